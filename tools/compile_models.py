@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Compile the in-scope robot URDFs into the JSON tables shipped under
+``legged_games_gym_amd/resources/models`` and extract the actuator-net weights.
+
+Run in the build container only (reads /root/reference, which never travels to
+the GPU box).  The URDFs are BSD-3 (ANYmal-C, ANYbotics) / MIT (Cassie,
+Agility Robotics) licensed data; the compiled tables are derived data.
+
+The TorchScript actuator net is NOT loaded or executed: the archive is opened
+as a zip, its ``data.pkl`` is *statically disassembled* with ``pickletools``
+(no object construction) to map tensor names to storage keys, and the raw
+little-endian float32 storages are copied.
+"""
+import io
+import json
+import os
+import pickletools
+import sys
+import zipfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.realpath(__file__))
+REPO = os.path.dirname(HERE)
+sys.path.insert(0, REPO)
+from legged_games_gym_amd.utils.model_compiler import compile_urdf  # noqa: E402
+
+REF = os.environ.get("LG_REFERENCE_DIR", "/root/reference")
+OUT = os.path.join(REPO, "legged_games_gym_amd", "resources")
+
+
+def models():
+    for stem, rel in (("anymal_c", "resources/robots/anymal_c/urdf/anymal_c.urdf"),
+                      ("cassie", "resources/robots/cassie/urdf/cassie.urdf")):
+        m = compile_urdf(os.path.join(REF, rel), name=stem)
+        path = os.path.join(OUT, "models", stem + ".json")
+        with open(path, "w") as fh:
+            fh.write(m.to_json())
+        print(f"{stem}: {m.num_bodies} bodies, {m.num_dof} dof, {m.num_shapes} shapes, "
+              f"K={m.num_limbs} L={m.chain_len}, mass {m.total_mass:.5f} kg -> {path}")
+
+
+def actuator_net():
+    src = os.path.join(REF, "resources/actuator_nets/anydrive_v3_lstm.pt")
+    z = zipfile.ZipFile(src)
+    top = z.namelist()[0].split("/")[0]
+    buf = io.StringIO()
+    pickletools.dis(z.read(f"{top}/data.pkl"), out=buf)
+    # walk the disassembly: a BINUNICODE attribute name is followed by its storage
+    # persistent-id tuple, whose key is the only all-digit string.
+    names, keys, last_name = [], [], None
+    wanted = {"in_scale", "out_scale", "weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0",
+              "weight_ih_l1", "weight_hh_l1", "bias_ih_l1", "bias_hh_l1", "weight", "bias"}
+    for line in buf.getvalue().splitlines():
+        if "BINUNICODE" not in line:
+            continue
+        s = line.split("BINUNICODE", 1)[1].strip().strip("'")
+        if s in wanted:
+            last_name = s
+        elif s.isdigit() and last_name is not None:     # only storage keys are digit strings
+            names.append(last_name)
+            keys.append(s)
+            last_name = None
+    table = dict(zip(names, keys))
+    assert len(table) == 12, table
+    shapes = {"in_scale": (2,), "out_scale": (1,), "weight_ih_l0": (32, 2), "weight_hh_l0": (32, 8),
+              "bias_ih_l0": (32,), "bias_hh_l0": (32,), "weight_ih_l1": (32, 8), "weight_hh_l1": (32, 8),
+              "bias_ih_l1": (32,), "bias_hh_l1": (32,), "weight": (1, 8), "bias": (1,)}
+    out = {}
+    for nm, key in table.items():
+        raw = np.frombuffer(z.read(f"{top}/data/{key}"), dtype="<f4")
+        assert raw.size == int(np.prod(shapes[nm])), (nm, raw.size)
+        out[nm] = raw.reshape(shapes[nm]).copy()
+    order = ["in_scale", "out_scale", "weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0",
+             "weight_ih_l1", "weight_hh_l1", "bias_ih_l1", "bias_hh_l1", "weight", "bias"]
+    flat = np.concatenate([out[k].ravel() for k in order]).astype("<f4")
+    dst = os.path.join(OUT, "actuator_nets", "anydrive_v3_lstm.f32")
+    flat.tofile(dst)
+    meta = {"layout": [{"name": ("linear_" + k if k in ("weight", "bias") else k), "shape": list(shapes[k])} for k in order],
+            "gate_order": "i,f,g,o (torch.nn.LSTM)", "source": "anydrive_v3_lstm.pt raw storages (BSD-3, ANYbotics)",
+            "num_floats": int(flat.size)}
+    with open(dst.replace(".f32", ".json"), "w") as fh:
+        json.dump(meta, fh, indent=1)
+    print(f"actuator net: {flat.size} floats -> {dst}; in_scale={out['in_scale']}, out_scale={out['out_scale']}")
+
+
+if __name__ == "__main__":
+    models()
+    actuator_net()
