@@ -1,0 +1,190 @@
+/*
+ * legged_hip.h -- C-ABI of the MI355X-native legged-robot hot path.
+ *
+ * This is the *inner* drop-in boundary of SURVEY.md section 8(b): it replaces
+ * the Isaac Gym tensor API calls the reference environment makes from
+ *   legged_gym/envs/base/legged_robot.py:80-137   (step / post_physics_step)
+ * plus the torch-side arithmetic between those calls, with one fused device
+ * launch per policy step.  Each entry point cites the reference call sites it
+ * stands in for.  No torch types appear here: all arrays are raw device
+ * pointers to buffers the caller (PyTorch-ROCm) allocated.
+ *
+ * The CPU oracle under oracle/ exports the same functions with the prefix
+ * `lgo_` over host pointers; it is test infrastructure only.
+ *
+ * Conventions: extern "C", opaque handle, fp32 / int32 / uint8 arrays,
+ * 0 = success, negative = error (text via lg_last_error()), no allocation
+ * inside lg_step, one handle per GPU, a handle is not thread-safe (the
+ * reference is single-threaded), the HIP stream is passed explicitly.
+ */
+#ifndef LEGGED_HIP_H
+#define LEGGED_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LG_ABI_VERSION        3
+
+#define LG_MAX_LIMBS          4
+#define LG_MAX_CHAIN          6
+#define LG_MAX_DOF            12
+#define LG_MAX_LIMB_POINTS    8
+#define LG_MAX_BASE_POINTS    4
+#define LG_MAX_BODIES         20
+#define LG_MAX_HEIGHT_POINTS  192
+#define LG_ACTUATOR_FLOATS    972
+
+/* Reward-term ids, ALPHABETICAL by name: the reference sums terms in dir()
+ * order (helpers.py:45, legged_robot.py:199-203).  `termination` is added
+ * after the only_positive clip (legged_robot.py:206-210). */
+enum lg_reward_term {
+    LG_REW_ACTION_RATE = 0, LG_REW_ANG_VEL_XY, LG_REW_BASE_HEIGHT, LG_REW_COLLISION,
+    LG_REW_DOF_ACC, LG_REW_DOF_POS_LIMITS, LG_REW_DOF_VEL, LG_REW_DOF_VEL_LIMITS,
+    LG_REW_FEET_AIR_TIME, LG_REW_FEET_CONTACT_FORCES, LG_REW_LIN_VEL_Z, LG_REW_NO_FLY,
+    LG_REW_ORIENTATION, LG_REW_STAND_STILL, LG_REW_STUMBLE, LG_REW_TERMINATION,
+    LG_REW_TORQUE_LIMITS, LG_REW_TORQUES, LG_REW_TRACKING_ANG_VEL, LG_REW_TRACKING_LIN_VEL,
+    LG_NUM_REWARD_TERMS
+};
+
+enum lg_control_type { LG_CTRL_P = 0, LG_CTRL_V = 1, LG_CTRL_T = 2, LG_CTRL_ACTUATOR_NET = 3 };
+enum lg_terrain_type { LG_TERRAIN_PLANE = 0, LG_TERRAIN_HEIGHTFIELD = 1 };
+
+/* A collision sphere rigidly attached to a dynamic body (a capsule = 2). */
+typedef struct lg_point {
+    float   pos[3];        /* in the carrying dynamic body's frame */
+    float   radius;
+    int32_t report_body;   /* row of contact_forces this point reports to */
+    int32_t joint;         /* index in the chain (0..L-1) of the carrying body; -1 = base */
+} lg_point;
+
+/* Robot = floating base + K serial limbs of L revolute joints (K*L == 12).
+ * Output of the model compiler (legged_games_gym_amd/utils/model_compiler.py),
+ * which stands in for gym.load_asset + get_asset_* (legged_robot.py:685-702). */
+typedef struct lg_robot_model {
+    int32_t num_limbs, chain_len, num_bodies, _pad0;
+    float   base_mass, base_com[3], base_inertia[6];      /* xx,xy,xz,yy,yz,zz at COM */
+    float   joint_pos[LG_MAX_DOF][3];                     /* joint origin in parent body frame */
+    float   joint_rot[LG_MAX_DOF][9];                     /* joint frame -> parent frame (q=0), row-major */
+    float   joint_axis[LG_MAX_DOF][3];                    /* unit axis in the joint frame */
+    float   body_mass[LG_MAX_DOF], body_com[LG_MAX_DOF][3], body_inertia[LG_MAX_DOF][6];
+    float   dof_lower[LG_MAX_DOF], dof_upper[LG_MAX_DOF]; /* hard limits (URDF); lower>upper = none */
+    float   dof_vel_limit[LG_MAX_DOF];
+    float   dof_armature[LG_MAX_DOF], dof_damping[LG_MAX_DOF];
+    int32_t num_base_points, num_limb_points[LG_MAX_LIMBS], _pad1[3];
+    lg_point base_points[LG_MAX_BASE_POINTS];
+    lg_point limb_points[LG_MAX_LIMBS][LG_MAX_LIMB_POINTS];
+    int32_t foot_body[LG_MAX_LIMBS];                      /* report body of each limb's foot (feet_indices) */
+    uint32_t penalised_mask, termination_mask;            /* bit b = report body b */
+} lg_robot_model;
+
+/* Everything LeggedRobotCfg / sim_params contribute to the hot path. */
+typedef struct lg_params {
+    int32_t abi_version, num_envs, decimation, control_type;
+    float   sim_dt, gravity[3];
+    /* contact + joint-limit model of the built-in rigid-body engine */
+    float   contact_stiffness, contact_damping, friction_damping, contact_margin;
+    float   ground_friction, limit_stiffness, limit_damping, _padf0;
+    /* control: legged_robot.py:371-395, anymal.py:71-81 */
+    float   action_scale, clip_actions, clip_observations, _padf1;
+    float   p_gains[LG_MAX_DOF], d_gains[LG_MAX_DOF], default_dof_pos[LG_MAX_DOF], torque_limits[LG_MAX_DOF];
+    /* soft limits for the reward terms: legged_robot.py:310-313, 914-930 */
+    float   soft_pos_lower[LG_MAX_DOF], soft_pos_upper[LG_MAX_DOF], dof_vel_limits[LG_MAX_DOF];
+    float   soft_dof_vel_limit, soft_torque_limit, tracking_sigma, base_height_target;
+    float   max_contact_force, dt_policy, max_push_vel, _padf2;
+    /* episode / commands: legged_robot.py:329-369, 781-791 */
+    int32_t max_episode_length, push_interval, resample_interval, heading_command;
+    float   cmd_lin_vel_x[2], cmd_lin_vel_y[2], cmd_ang_vel_yaw[2], cmd_heading[2];
+    /* observations: legged_robot.py:212-230, 485-508 */
+    float   obs_scale_lin_vel, obs_scale_ang_vel, obs_scale_dof_pos, obs_scale_dof_vel, obs_scale_height;
+    float   noise_lin_vel, noise_ang_vel, noise_gravity, noise_dof_pos, noise_dof_vel, noise_height; /* already x level x obs scale */
+    int32_t add_noise, measure_heights, num_height_points, num_obs;
+    float   height_points[LG_MAX_HEIGHT_POINTS][2];
+    /* rewards: legged_robot.py:193-210, 583-607; scale already multiplied by dt, 0 = term absent */
+    float   reward_scale[LG_NUM_REWARD_TERMS];
+    int32_t only_positive_rewards, reward_slot[LG_NUM_REWARD_TERMS]; /* row of episode_sums, -1 = absent */
+    int32_t num_reward_slots;
+    /* terrain: legged_robot.py:609-637, 831-869; terrain.py */
+    int32_t terrain_type, hf_rows, hf_cols, custom_origins;
+    float   hf_horizontal_scale, hf_vertical_scale, hf_border, _padf3;
+    int32_t terrain_curriculum, terrain_num_rows, terrain_num_cols, _padi0;
+    float   terrain_env_length, max_episode_length_s;
+    /* reset: legged_robot.py:397-436 */
+    float   base_init_state[13], _padf4;
+    uint64_t seed;
+} lg_params;
+
+/* Raw device pointers to caller-owned (torch-allocated) buffers.  Layouts are
+ * the reference's so the Python views stay valid. */
+typedef struct lg_buffers {
+    float   *root_states;       /* [N,13] pos, quat xyzw, lin vel, ang vel (world)       T1 */
+    float   *dof_state;         /* [N*ndof,2] (pos,vel) interleaved                      T2 */
+    float   *contact_forces;    /* [N,num_bodies,3]                                      T3 */
+    float   *obs_buf;           /* [N,num_obs]                                           T4 */
+    float   *rew_buf;           /* [N] */
+    uint8_t *reset_buf;         /* [N] bool */
+    uint8_t *time_out_buf;      /* [N] bool */
+    int64_t *episode_length_buf;/* [N] */
+    float   *torques, *actions, *last_actions, *last_dof_vel;   /* [N,ndof]              T5 */
+    float   *last_root_vel;     /* [N,6] */
+    float   *commands;          /* [N,4] */
+    float   *feet_air_time;     /* [N,K] */
+    uint8_t *last_contacts;     /* [N,K] bool */
+    float   *base_lin_vel, *base_ang_vel, *projected_gravity;   /* [N,3] */
+    float   *measured_heights;  /* [N,num_height_points] or NULL */
+    float   *sea_hidden_state, *sea_cell_state;                 /* [2,N*ndof,8] or NULL  T6 */
+    float   *episode_sums;      /* [num_reward_slots,N]                                  T7 */
+    float   *episode_sums_done; /* [num_reward_slots,N] sums of envs reset this step (for extras) */
+    float   *env_origins;       /* [N,3] */
+    int32_t *terrain_levels, *terrain_types;                    /* [N] or NULL           T9 */
+    const float   *terrain_origins;   /* [rows,cols,3] or NULL */
+    const int16_t *height_samples;    /* [hf_rows,hf_cols] or NULL                       T8 */
+    const float   *friction_coeffs;   /* [N] per-env shape friction (legged_robot.py:261-285) */
+    const float   *base_mass_delta;   /* [N] added base mass (legged_robot.py:316-327) */
+} lg_buffers;
+
+typedef struct lg_sim lg_sim;
+
+/* create_sim + prepare_sim (base_task.py:42,88; legged_robot.py:232-251, 657-750):
+ * copies model, params and the actuator weights to the device. */
+int  lg_create(const lg_params *params, const lg_robot_model *model,
+               const float *actuator_weights /* LG_ACTUATOR_FLOATS or NULL */,
+               int device_id, lg_sim **out);
+void lg_destroy(lg_sim *sim);
+
+/* acquire_*_tensor + wrap_tensor (legged_robot.py:515-529): bind caller buffers. */
+int  lg_bind(lg_sim *sim, const lg_buffers *buffers);
+
+/* LeggedRobot.step (legged_robot.py:80-104) for all envs, fused:
+ *   clip actions; decimation x (_compute_torques -> set_dof_actuation_force ->
+ *   simulate -> refresh_dof_state); post_physics_step (incl. reset_idx for
+ *   terminated envs and compute_observations); clip obs.
+ * `actions` is [N,ndof] on the device.  `common_step_counter` is the value
+ * AFTER the increment of legged_robot.py:115.  Asynchronous on `stream`. */
+int  lg_step(lg_sim *sim, const float *actions, int64_t common_step_counter, void *stream);
+
+/* reset_idx on an explicit env list (base_task.py:114-118 reset(); device int32 ids). */
+int  lg_reset_idx(lg_sim *sim, const int32_t *env_ids, int32_t count,
+                  int64_t common_step_counter, void *stream);
+
+/* Sub-path entry points (parity tests drive them one at a time). */
+int  lg_actuator_forward(lg_sim *sim, const float *pos_err, const float *vel, float *torques,
+                         float *hidden, float *cell, int32_t rows, void *stream);       /* anymal.py:71-78 */
+int  lg_physics_substep(lg_sim *sim, const float *torques, int32_t write_contacts, void *stream); /* legged_robot.py:92-96 */
+int  lg_compute_observations_only(lg_sim *sim, int64_t common_step_counter, void *stream);        /* legged_robot.py:212-230 */
+
+/* Update params that the Python surface may change between steps
+ * (command ranges by the curriculum, legged_robot.py:471-483). */
+int  lg_set_params(lg_sim *sim, const lg_params *params);
+
+const char *lg_last_error(void);
+int  lg_abi_version(void);
+/* sizeof of the ABI structs (0 params, 1 robot_model, 2 buffers, 3 point) so a binding can verify its layout. */
+int  lg_sizeof(int which);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LEGGED_HIP_H */

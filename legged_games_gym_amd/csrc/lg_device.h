@@ -1,0 +1,239 @@
+// lg_device.h -- device-side building blocks of the fused legged-robot step (gfx950, wave64).
+//
+// Layout: K lanes per environment, one lane per limb ("limb-per-lane").  A limb
+// is a serial chain of L revolute joints hanging off the floating base; the
+// lane owns that chain's kinematics, articulated-body recursion, contacts,
+// actuator-net rows, reward partial sums and observation slots.  The base is
+// shared: the K lanes of an environment butterfly-sum their limb's articulated
+// inertia / bias force with DPP quad permutes and every lane then solves the
+// same 6x6 base system redundantly (no broadcast, no LDS, no divergence).
+//
+// Math follows DESIGN.md "Physics step"; the CPU oracle (oracle/lg_oracle.c)
+// is an independent scalar coding of the same equations.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/legged_hip.h"
+
+#define LG_DEV __device__ __forceinline__
+
+namespace lg {
+
+// ------------------------------------------------------------------ small vectors
+struct V3 { float x, y, z; };
+LG_DEV V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+LG_DEV V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+LG_DEV V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+LG_DEV V3 operator*(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+LG_DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+LG_DEV V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+struct M3 { float m[9]; };                       // row-major
+LG_DEV V3 mul(const M3 &R, V3 a) {
+    return v3(R.m[0] * a.x + R.m[1] * a.y + R.m[2] * a.z, R.m[3] * a.x + R.m[4] * a.y + R.m[5] * a.z,
+              R.m[6] * a.x + R.m[7] * a.y + R.m[8] * a.z);
+}
+LG_DEV M3 mul(const M3 &A, const M3 &B) {
+    M3 C;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) C.m[3 * i + j] = A.m[3 * i] * B.m[j] + A.m[3 * i + 1] * B.m[3 + j] + A.m[3 * i + 2] * B.m[6 + j];
+    return C;
+}
+LG_DEV V3 symv(const float *S, V3 a) {           // (xx,xy,xz,yy,yz,zz)
+    return v3(S[0] * a.x + S[1] * a.y + S[2] * a.z, S[1] * a.x + S[3] * a.y + S[4] * a.z, S[2] * a.x + S[4] * a.y + S[5] * a.z);
+}
+struct S6 { V3 w, v; };                          // spatial motion (w,v) / force (n,f)
+LG_DEV S6 operator+(S6 a, S6 b) { S6 r; r.w = a.w + b.w; r.v = a.v + b.v; return r; }
+LG_DEV S6 operator*(S6 a, float k) { S6 r; r.w = a.w * k; r.v = a.v * k; return r; }
+LG_DEV float dot(S6 a, S6 b) { return dot(a.w, b.w) + dot(a.v, b.v); }
+
+// articulated inertia [[A,H],[H^T,M]] about the base origin, world axes
+struct AI { float A[6], H[9], M[6]; };
+LG_DEV void ai_add(AI &a, const AI &b) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) { a.A[i] += b.A[i]; a.M[i] += b.M[i]; }
+#pragma unroll
+    for (int i = 0; i < 9; i++) a.H[i] += b.H[i];
+}
+LG_DEV void ai_add_point(AI &I, float m, V3 c) {
+    float cc = dot(c, c);
+    I.A[0] += m * (cc - c.x * c.x); I.A[1] -= m * c.x * c.y; I.A[2] -= m * c.x * c.z;
+    I.A[3] += m * (cc - c.y * c.y); I.A[4] -= m * c.y * c.z; I.A[5] += m * (cc - c.z * c.z);
+    I.H[1] -= m * c.z; I.H[2] += m * c.y; I.H[3] += m * c.z; I.H[5] -= m * c.x; I.H[6] -= m * c.y; I.H[7] += m * c.x;
+    I.M[0] += m; I.M[3] += m; I.M[5] += m;
+}
+LG_DEV void ai_add_rank1(AI &I, float k, V3 gw, V3 gv) {
+    float w[3] = {gw.x, gw.y, gw.z}, v[3] = {gv.x, gv.y, gv.z};
+    int t = 0;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = i; j < 3; j++, t++) { I.A[t] += k * w[i] * w[j]; I.M[t] += k * v[i] * v[j]; }
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) I.H[3 * i + j] += k * w[i] * v[j];
+}
+LG_DEV S6 ai_mul(const AI &I, S6 s) {
+    S6 r;
+    M3 H; for (int i = 0; i < 9; i++) H.m[i] = I.H[i];
+    r.w = symv(I.A, s.w) + mul(H, s.v);
+    r.v = v3(I.H[0] * s.w.x + I.H[3] * s.w.y + I.H[6] * s.w.z, I.H[1] * s.w.x + I.H[4] * s.w.y + I.H[7] * s.w.z,
+             I.H[2] * s.w.x + I.H[5] * s.w.y + I.H[8] * s.w.z) + symv(I.M, s.v);
+    return r;
+}
+
+// SPD 6x6 solve by LDL^T, fully unrolled (registers only)
+LG_DEV bool solve6(const AI &I, const float *b, float *x) {
+    float m[6][6];
+    const int ix[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            m[i][j] = I.A[ix[i][j]]; m[i + 3][j + 3] = I.M[ix[i][j]];
+            m[i][j + 3] = I.H[3 * i + j]; m[j + 3][i] = I.H[3 * i + j];
+        }
+    float Lm[6][6], D[6];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        float d = m[j][j];
+#pragma unroll
+        for (int k = 0; k < j; k++) d -= Lm[j][k] * Lm[j][k] * D[k];
+        ok = ok && (d > 0.0f);
+        D[j] = d;
+#pragma unroll
+        for (int i = j + 1; i < 6; i++) {
+            float v = m[i][j];
+#pragma unroll
+            for (int k = 0; k < j; k++) v -= Lm[i][k] * Lm[j][k] * D[k];
+            Lm[i][j] = v / d;
+        }
+    }
+    float y[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) { float v = b[i];
+#pragma unroll
+        for (int k = 0; k < i; k++) v -= Lm[i][k] * y[k];
+        y[i] = v; }
+#pragma unroll
+    for (int i = 0; i < 6; i++) y[i] /= D[i];
+#pragma unroll
+    for (int i = 5; i >= 0; i--) { float v = y[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; k++) v -= Lm[k][i] * x[k];
+        x[i] = v; }
+    return ok;
+}
+
+LG_DEV M3 quat_to_mat(const float *q) {
+    float x = q[0], y = q[1], z = q[2], w = q[3];
+    M3 R;
+    R.m[0] = 1 - 2 * (y * y + z * z); R.m[1] = 2 * (x * y - z * w);     R.m[2] = 2 * (x * z + y * w);
+    R.m[3] = 2 * (x * y + z * w);     R.m[4] = 1 - 2 * (x * x + z * z); R.m[5] = 2 * (y * z - x * w);
+    R.m[6] = 2 * (x * z - y * w);     R.m[7] = 2 * (y * z + x * w);     R.m[8] = 1 - 2 * (x * x + y * y);
+    return R;
+}
+// isaacgym.torch_utils.quat_rotate_inverse / quat_apply ([EXTERNAL]; legged_robot.py:119-121,338)
+LG_DEV V3 quat_rotate_inverse(const float *q, V3 v) {
+    float qw = q[3]; V3 qv = v3(q[0], q[1], q[2]);
+    V3 a = v * (2.0f * qw * qw - 1.0f);
+    V3 b = cross(qv, v) * (qw * 2.0f);
+    V3 c = qv * (dot(qv, v) * 2.0f);
+    return (a - b) + c;
+}
+LG_DEV V3 quat_apply(const float *q, V3 b) {
+    V3 xyz = v3(q[0], q[1], q[2]);
+    V3 t = cross(xyz, b) * 2.0f;
+    return (b + t * q[3]) + cross(xyz, t);
+}
+
+// ------------------------------------------------------------------ cross-lane (DPP quad permutes; K in {1,2,4})
+template <int CTRL> LG_DEV float dpp(float x) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), CTRL, 0xF, 0xF, true));
+}
+template <int K> LG_DEV float group_sum(float x) {      // butterfly; every lane of the group gets (x0+x1)+(x2+x3)
+    if (K >= 2) x = x + dpp<0xB1>(x);                   // quad_perm [1,0,3,2]
+    if (K >= 4) x = x + dpp<0x4E>(x);                   // quad_perm [2,3,0,1]
+    return x;
+}
+template <int K> LG_DEV int group_or(int x) {
+    if (K >= 2) x |= __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true);
+    if (K >= 4) x |= __builtin_amdgcn_mov_dpp(x, 0x4E, 0xF, 0xF, true);
+    return x;
+}
+template <int K> LG_DEV void group_sum(AI &I, S6 &p) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) { I.A[i] = group_sum<K>(I.A[i]); I.M[i] = group_sum<K>(I.M[i]); }
+#pragma unroll
+    for (int i = 0; i < 9; i++) I.H[i] = group_sum<K>(I.H[i]);
+    p.w.x = group_sum<K>(p.w.x); p.w.y = group_sum<K>(p.w.y); p.w.z = group_sum<K>(p.w.z);
+    p.v.x = group_sum<K>(p.v.x); p.v.y = group_sum<K>(p.v.y); p.v.z = group_sum<K>(p.v.z);
+}
+
+// ------------------------------------------------------------------ Philox4x32-10 (same stream as the oracle)
+enum { RNG_NOISE = 0, RNG_CMD_STEP = 1, RNG_CMD_RESET = 2, RNG_DOF = 3, RNG_ROOT = 4, RNG_PUSH = 5, RNG_TERRAIN = 6, RNG_NOISE_H = 7 };
+LG_DEV void rand4(uint64_t seed, int env, int64_t step, int purpose, int block, float u[4]) {
+    uint32_t c0 = (uint32_t)env, c1 = (uint32_t)step, c2 = (uint32_t)purpose, c3 = (uint32_t)block;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    u[0] = (float)(c0 >> 8) * (1.0f / 16777216.0f); u[1] = (float)(c1 >> 8) * (1.0f / 16777216.0f);
+    u[2] = (float)(c2 >> 8) * (1.0f / 16777216.0f); u[3] = (float)(c3 >> 8) * (1.0f / 16777216.0f);
+}
+LG_DEV float urange(float lo, float hi, float u) { return (hi - lo) * u + lo; }
+
+// ------------------------------------------------------------------ ANYdrive actuator net (anymal.py:71-78)
+// Weights are read through the constant address space so every weight is an
+// SGPR operand of a v_fma (scalar loads, no VGPR / LDS traffic).
+typedef const float __attribute__((address_space(4))) *cfp;
+LG_DEV float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.442695041f * x)); }
+LG_DEV float fast_tanh(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.885390082f * x)) - 1.0f; }
+
+struct LstmState { float h0[8], c0[8], h1[8], c1[8]; };
+
+LG_DEV float actuator_row(cfp W, float pos_err, float vel, LstmState &s) {
+    cfp Wih0 = W + 3, Whh0 = Wih0 + 64, bih0 = Whh0 + 256, bhh0 = bih0 + 32;
+    cfp Wih1 = bhh0 + 32, Whh1 = Wih1 + 256, bih1 = Whh1 + 256, bhh1 = bih1 + 32;
+    cfp lw = bhh1 + 32, lb = lw + 8;
+    float x0 = pos_err * W[0], x1 = vel * W[1];
+    float g[32];
+#pragma unroll
+    for (int r = 0; r < 32; r++) {
+        float a = Wih0[2 * r] * x0 + Wih0[2 * r + 1] * x1 + bih0[r];
+        float b = bhh0[r];
+#pragma unroll
+        for (int k = 0; k < 8; k++) b += Whh0[8 * r + k] * s.h0[k];
+        g[r] = a + b;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        float c = fast_sigmoid(g[8 + u]) * s.c0[u] + fast_sigmoid(g[u]) * fast_tanh(g[16 + u]);
+        s.c0[u] = c; s.h0[u] = fast_sigmoid(g[24 + u]) * fast_tanh(c);
+    }
+#pragma unroll
+    for (int r = 0; r < 32; r++) {
+        float a = bih1[r], b = bhh1[r];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { a += Wih1[8 * r + k] * s.h0[k]; b += Whh1[8 * r + k] * s.h1[k]; }
+        g[r] = a + b;
+    }
+    float y = lb[0];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        float c = fast_sigmoid(g[8 + u]) * s.c1[u] + fast_sigmoid(g[u]) * fast_tanh(g[16 + u]);
+        s.c1[u] = c; s.h1[u] = fast_sigmoid(g[24 + u]) * fast_tanh(c);
+        y += lw[u] * s.h1[u];
+    }
+    return W[2] * y;
+}
+
+}  // namespace lg

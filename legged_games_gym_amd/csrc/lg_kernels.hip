@@ -1,0 +1,1122 @@
+// lg_kernels.hip -- fused LeggedRobot.step() for gfx950 + the C-ABI of include/legged_hip.h.
+//
+// One launch per policy step does what reference legged_gym/envs/base/legged_robot.py:80-137
+// does with ~150 eager torch kernels and 4 PhysX steps:
+//   clip actions -> decimation x [actuator net / PD torque -> articulated-body step with
+//   implicit contacts] -> post_physics_step (base-frame quantities, command resampling,
+//   height sampling, pushes, termination, the _reward_* sum, predicated reset_idx,
+//   compute_observations with noise, last_* bookkeeping) -> clip observations.
+// Persistent state is read once and written once per env-step.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -shared -fPIC lg_kernels.hip -o liblegged_hip.so
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <new>
+
+#include "lg_device.h"
+
+using namespace lg;
+
+#define LG_BLOCK 64            // one wave per workgroup: 4096 envs x 4 limbs = 256 waves = one per CU
+#define LG_JS 40               // floats per joint in the LDS limb table
+#define LG_PASSES 2
+
+// ------------------------------------------------------------------ robot topologies compiled in
+struct AnymalTraits {          // base + 4 legs x (HAA,HFE,KFE); points: thigh capsule, shank capsule, foot sphere
+    static constexpr int K = 4, L = 3, NBASE = 2, NREP = 4, NPT = 5;
+    static constexpr int pt_joint(int i) { return i < 2 ? 1 : 2; }
+    static constexpr int pt_rep(int i) { return i < 2 ? 1 : (i < 4 ? 2 : 3); }
+    static constexpr int FOOT_REP = 3;
+};
+struct CassieTraits {          // pelvis + 2 legs x 6 joints; points: toe capsule
+    static constexpr int K = 2, L = 6, NBASE = 1, NREP = 6, NPT = 2;
+    static constexpr int pt_joint(int) { return 5; }
+    static constexpr int pt_rep(int) { return 5; }
+    static constexpr int FOOT_REP = 5;
+};
+template <class T> struct Tab { static constexpr int STRIDE = T::L * LG_JS + 4 * T::NPT + 1; };
+// per-joint offsets inside the limb table
+enum { J_POS = 0, J_ROT = 3, J_AXIS = 12, J_MASS = 15, J_COM = 16, J_INERTIA = 19, J_LO = 25, J_HI = 26, J_VLIM = 27,
+       J_ARM = 28, J_DAMP = 29, J_KP = 30, J_KD = 31, J_Q0 = 32, J_TLIM = 33, J_SLO = 34, J_SHI = 35, J_DVL = 36 };
+
+struct BaseTab { float mass, com[3], inertia[6]; float pts[LG_MAX_BASE_POINTS][4]; };
+
+struct KArgs {                 // passed by value: lives in the kernarg segment -> scalar loads
+    lg_params  P;
+    lg_buffers B;
+    BaseTab    base;
+    const float *limb_table;   // [K][STRIDE] device
+    const float *weights;      // [972] device or null
+    const float *actions_in;   // [N, ndof]
+    const int32_t *env_ids;    // reset kernel only
+    int32_t    count;
+    uint32_t   penalised_mask, termination_mask;
+    int64_t    step;
+};
+
+// ------------------------------------------------------------------ terrain
+template <bool HF> LG_DEV void ground_query(const KArgs &A, float x, float y, float &h, V3 &n) {
+    if (!HF) { h = 0.0f; n = v3(0, 0, 1); return; }
+    const lg_params &P = A.P;
+    float inv = 1.0f / P.hf_horizontal_scale;
+    float gx = (x + P.hf_border) * inv, gy = (y + P.hf_border) * inv;
+    float fx = floorf(gx), fy = floorf(gy);
+    int ix = (int)fx, iy = (int)fy;
+    float tx = gx - fx, ty = gy - fy;
+    auto at = [&](int i, int j) {
+        i = min(max(i, 0), P.hf_rows - 1); j = min(max(j, 0), P.hf_cols - 1);
+        return (float)A.B.height_samples[(size_t)i * P.hf_cols + j] * P.hf_vertical_scale;
+    };
+    float h00 = at(ix, iy), h10 = at(ix + 1, iy), h01 = at(ix, iy + 1), h11 = at(ix + 1, iy + 1);
+    float hx0 = h00 + (h10 - h00) * tx, hx1 = h01 + (h11 - h01) * tx;
+    h = hx0 + (hx1 - hx0) * ty;
+    float dhdx = ((h10 - h00) + ((h11 - h01) - (h10 - h00)) * ty) * inv;
+    float dhdy = (hx1 - hx0) * inv;
+    float l = 1.0f / sqrtf(dhdx * dhdx + dhdy * dhdy + 1.0f);
+    n = v3(-dhdx * l, -dhdy * l, l);
+}
+
+// ------------------------------------------------------------------ one 5 ms rigid-body step for (env, limb)
+struct Contact { V3 r, n, vc, f; float depth, bt; bool on; };
+
+LG_DEV void contact_setup(Contact &c, const lg_params &P, V3 r, V3 n, float depth, V3 vc) {
+    c.r = r; c.n = n; c.depth = depth; c.vc = vc; c.on = depth > -P.contact_margin;
+    c.bt = P.friction_damping; c.f = v3(0, 0, 0);
+}
+LG_DEV void contact_assemble(const Contact &c, const lg_params &P, float kn, AI &IA, S6 &pA) {
+    if (c.on) {
+        const float dt = P.sim_dt;
+        float vn = dot(c.n, c.vc);
+        V3 vt = c.vc - c.n * vn;
+        V3 f = c.n * (P.contact_stiffness * c.depth - kn * vn) - vt * c.bt;
+        ai_add_point(IA, dt * c.bt, c.r);
+        ai_add_rank1(IA, dt * (kn - c.bt), cross(c.r, c.n), c.n);
+        pA.w = pA.w - cross(c.r, f);
+        pA.v = pA.v - f;
+    }
+}
+LG_DEV void contact_evaluate(Contact &c, const lg_params &P, float kn, float mu, S6 acc) {
+    if (c.on) {
+        V3 v1 = c.vc + (acc.v + cross(acc.w, c.r)) * P.sim_dt;
+        float vn = dot(c.n, v1);
+        V3 vt = v1 - c.n * vn;
+        float fn = P.contact_stiffness * c.depth - kn * vn;
+        if (fn <= 0.0f) { c.on = false; c.f = v3(0, 0, 0); }
+        else {
+            float vtn = sqrtf(dot(vt, vt)), ft = c.bt * vtn;
+            if (ft > mu * fn) { c.bt = mu * fn / fmaxf(vtn, 1e-9f); ft = mu * fn; }
+            V3 tdir = (vtn > 1e-12f) ? vt * (1.0f / vtn) : v3(0, 0, 0);
+            c.f = c.n * fn - tdir * ft;
+        }
+    }
+}
+
+template <class T, bool HF>
+LG_DEV void physics_substep(const KArgs &A, const float *tab, float (&root)[13], float (&q)[T::L], float (&qd)[T::L],
+                            const float (&tau)[T::L], float base_mass, float mu,
+                            float (&Frep)[T::NREP][3], float (&Fbase)[3]) {
+    constexpr int K = T::K, L = T::L, NPT = T::NPT, NBASE = T::NBASE;
+    const lg_params &P = A.P;
+    const float dt = P.sim_dt;
+    const V3 grav = v3(P.gravity[0], P.gravity[1], P.gravity[2]);
+    const float kn = P.contact_stiffness * dt + P.contact_damping;
+
+    // ---- kinematics (world axes, positions relative to the base origin)
+    const M3 R0 = quat_to_mat(root + 3);
+    const V3 w0 = v3(root[10], root[11], root[12]), v0 = v3(root[7], root[8], root[9]);
+    V3 rb[L], wb[L], vb[L];
+    M3 Rb[L];
+    S6 S[L], C[L];
+#pragma unroll
+    for (int j = 0; j < L; j++) {
+        const float *tj = tab + j * LG_JS;
+        const V3 rpar = j ? rb[j ? j - 1 : 0] : v3(0, 0, 0), wpar = j ? wb[j ? j - 1 : 0] : w0, vpar = j ? vb[j ? j - 1 : 0] : v0;
+        const M3 &Rpar = j ? Rb[j ? j - 1 : 0] : R0;
+        rb[j] = rpar + mul(Rpar, v3(tj[J_POS], tj[J_POS + 1], tj[J_POS + 2]));
+        M3 Rfix;
+#pragma unroll
+        for (int i = 0; i < 9; i++) Rfix.m[i] = tj[J_ROT + i];
+        const M3 Rz = mul(Rpar, Rfix);
+        const V3 ax = mul(Rz, v3(tj[J_AXIS], tj[J_AXIS + 1], tj[J_AXIS + 2]));
+        float sn, cs;
+        sincosf(q[j], &sn, &cs);
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            V3 col = v3(Rz.m[c], Rz.m[3 + c], Rz.m[6 + c]);
+            V3 rot = (col * cs + cross(ax, col) * sn) + ax * (dot(ax, col) * (1.0f - cs));
+            Rb[j].m[c] = rot.x; Rb[j].m[3 + c] = rot.y; Rb[j].m[6 + c] = rot.z;
+        }
+        S[j].w = ax; S[j].v = cross(rb[j], ax);
+        wb[j] = wpar + ax * qd[j];
+        vb[j] = vpar + S[j].v * qd[j];
+        C[j].w = cross(wb[j], S[j].w) * qd[j];
+        C[j].v = (cross(wb[j], S[j].v) + cross(vb[j], S[j].w)) * qd[j];
+    }
+
+    // ---- rigid-body inertia about O and bias force (gyroscopic - gravity) of one body
+    auto body_terms = [&](float m, V3 com_l, const float *Il, const M3 &R, V3 r, V3 w, V3 v, AI &I0, S6 &p0) {
+        V3 c = r + mul(R, com_l);
+        M3 Ilf; Ilf.m[0] = Il[0]; Ilf.m[1] = Il[1]; Ilf.m[2] = Il[2]; Ilf.m[3] = Il[1]; Ilf.m[4] = Il[3]; Ilf.m[5] = Il[4];
+        Ilf.m[6] = Il[2]; Ilf.m[7] = Il[4]; Ilf.m[8] = Il[5];
+        M3 Rt;
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j2 = 0; j2 < 3; j2++) Rt.m[3 * i + j2] = R.m[3 * j2 + i];
+        M3 Ic = mul(mul(R, Ilf), Rt);
+#pragma unroll
+        for (int i = 0; i < 9; i++) I0.H[i] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 6; i++) I0.M[i] = 0.0f;
+        I0.A[0] = Ic.m[0]; I0.A[1] = Ic.m[1]; I0.A[2] = Ic.m[2]; I0.A[3] = Ic.m[4]; I0.A[4] = Ic.m[5]; I0.A[5] = Ic.m[8];
+        ai_add_point(I0, m, c);
+        V3 l = (v + cross(w, c)) * m;
+        V3 n = mul(Ic, w) + cross(c, l);
+        V3 fg = grav * m;
+        p0.w = (cross(w, n) + cross(v, l)) - cross(c, fg);
+        p0.v = cross(w, l) - fg;
+    };
+    AI I0[L], I0b;
+    S6 p0[L], p0b;
+#pragma unroll
+    for (int j = 0; j < L; j++) {
+        const float *tj = tab + j * LG_JS;
+        float Il[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) Il[i] = tj[J_INERTIA + i];
+        body_terms(tj[J_MASS], v3(tj[J_COM], tj[J_COM + 1], tj[J_COM + 2]), Il, Rb[j], rb[j], wb[j], vb[j], I0[j], p0[j]);
+    }
+    {
+        float sc = base_mass / A.base.mass, Il[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) Il[i] = A.base.inertia[i] * sc;
+        body_terms(base_mass, v3(A.base.com[0], A.base.com[1], A.base.com[2]), Il, R0, v3(0, 0, 0), w0, v0, I0b, p0b);
+    }
+
+    // ---- contact candidates: base points (every lane, redundantly) and this limb's points
+    Contact cb[NBASE], cl[NPT];
+#pragma unroll
+    for (int i = 0; i < NBASE; i++) {
+        V3 r = mul(R0, v3(A.base.pts[i][0], A.base.pts[i][1], A.base.pts[i][2]));
+        float h; V3 n;
+        ground_query<HF>(A, root[0] + r.x, root[1] + r.y, h, n);
+        contact_setup(cb[i], P, r, n, A.base.pts[i][3] - (root[2] + r.z - h) * n.z, v0 + cross(w0, r));
+    }
+#pragma unroll
+    for (int i = 0; i < NPT; i++) {
+        const int j = T::pt_joint(i);
+        const float *tp = tab + L * LG_JS + 4 * i;
+        V3 r = rb[j] + mul(Rb[j], v3(tp[0], tp[1], tp[2]));
+        float h; V3 n;
+        ground_query<HF>(A, root[0] + r.x, root[1] + r.y, h, n);
+        contact_setup(cl[i], P, r, n, tp[3] - (root[2] + r.z - h) * n.z, vb[j] + cross(wb[j], r));
+    }
+
+    // ---- articulated-body passes with the contact impedances folded in
+    S6 U[L], acc0;
+    float Dinv[L], uu[L];
+#pragma unroll 1
+    for (int pass = 0; pass < LG_PASSES; pass++) {
+        AI Ia; S6 pa;
+#pragma unroll
+        for (int j = L - 1; j >= 0; j--) {
+            const float *tj = tab + j * LG_JS;
+            AI IA = I0[j]; S6 pA = p0[j];
+#pragma unroll
+            for (int i = 0; i < NPT; i++) if (T::pt_joint(i) == j) contact_assemble(cl[i], P, kn, IA, pA);
+            if (j < L - 1) { ai_add(IA, Ia); pA = pA + pa; }
+            U[j] = ai_mul(IA, S[j]);
+            float damp = tj[J_DAMP];
+            float D = dot(S[j], U[j]) + tj[J_ARM] + dt * damp;
+            float u = tau[j] - dot(S[j], pA) - damp * qd[j];
+            float lo = tj[J_LO], hi = tj[J_HI];
+            if (lo <= hi) {
+                float qp = q[j] + dt * qd[j];
+                bool blo = qp < lo, bhi = qp > hi;
+                if (blo || bhi) {
+                    float viol = q[j] - (blo ? lo : hi);
+                    float kl = P.limit_stiffness * dt + P.limit_damping;
+                    D += dt * kl;
+                    u += -P.limit_stiffness * viol - kl * qd[j];
+                }
+            }
+            Dinv[j] = 1.0f / D; uu[j] = u;
+            Ia = IA;
+            ai_add_rank1(Ia, -Dinv[j], U[j].w, U[j].v);
+            pa = (pA + ai_mul(Ia, C[j])) + U[j] * (u * Dinv[j]);
+        }
+        group_sum<K>(Ia, pa);                     // (limb0+limb1)+(limb2+limb3) on every lane of the env
+        AI IAb = I0b; S6 pAb = p0b;
+#pragma unroll
+        for (int i = 0; i < NBASE; i++) contact_assemble(cb[i], P, kn, IAb, pAb);
+        ai_add(IAb, Ia); pAb = pAb + pa;
+        float rhs[6] = {-pAb.w.x, -pAb.w.y, -pAb.w.z, -pAb.v.x, -pAb.v.y, -pAb.v.z}, a0[6];
+        bool ok = solve6(IAb, rhs, a0);
+        if (!ok) { a0[0] = a0[1] = a0[2] = a0[3] = a0[4] = a0[5] = 0.0f; }
+        acc0.w = v3(a0[0], a0[1], a0[2]); acc0.v = v3(a0[3], a0[4], a0[5]);
+#pragma unroll
+        for (int i = 0; i < NBASE; i++) contact_evaluate(cb[i], P, kn, mu, acc0);
+        S6 a = acc0;
+#pragma unroll
+        for (int j = 0; j < L; j++) {
+            S6 ap = a + C[j];
+            float qdd = (uu[j] - dot(U[j], ap)) * Dinv[j];
+            a = ap + S[j] * qdd;
+            uu[j] = qdd;
+#pragma unroll
+            for (int i = 0; i < NPT; i++) if (T::pt_joint(i) == j) contact_evaluate(cl[i], P, kn, mu, a);
+        }
+    }
+
+    // ---- semi-implicit Euler
+#pragma unroll
+    for (int j = 0; j < L; j++) {
+        float v = qd[j] + dt * uu[j];
+        float lim = tab[j * LG_JS + J_VLIM];
+        if (lim > 0.0f) v = fminf(fmaxf(v, -lim), lim);
+        qd[j] = v;
+        q[j] += dt * v;
+    }
+    {
+        V3 a_lin = acc0.v + cross(w0, v0);
+        V3 w1 = w0 + acc0.w * dt, v1 = v0 + a_lin * dt;
+        root[7] = v1.x; root[8] = v1.y; root[9] = v1.z; root[10] = w1.x; root[11] = w1.y; root[12] = w1.z;
+        root[0] += dt * v1.x; root[1] += dt * v1.y; root[2] += dt * v1.z;
+        float x = root[3], y = root[4], z = root[5], w = root[6], hx = 0.5f * dt * w1.x, hy = 0.5f * dt * w1.y, hz = 0.5f * dt * w1.z;
+        float nx = x + (hx * w + hy * z - hz * y), ny = y + (hy * w + hz * x - hx * z), nz = z + (hz * w + hx * y - hy * x);
+        float nw = w - (hx * x + hy * y + hz * z);
+        float inv = 1.0f / sqrtf(nx * nx + ny * ny + nz * nz + nw * nw);
+        root[3] = nx * inv; root[4] = ny * inv; root[5] = nz * inv; root[6] = nw * inv;
+    }
+    // ---- net contact force per report body of this limb, and of the base
+#pragma unroll
+    for (int r = 0; r < T::NREP; r++) {
+        V3 f = v3(0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NPT; i++) if (T::pt_rep(i) == r) f = f + cl[i].f;
+        Frep[r][0] = f.x; Frep[r][1] = f.y; Frep[r][2] = f.z;
+    }
+    {
+        V3 f = v3(0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NBASE; i++) f = f + cb[i].f;
+        Fbase[0] = f.x; Fbase[1] = f.y; Fbase[2] = f.z;
+    }
+}
+
+// ------------------------------------------------------------------ torques (legged_robot.py:371-395)
+template <int L> LG_DEV void pd_torques(const lg_params &P, const float *tab, const float (&act)[L], const float (&q)[L],
+                                        const float (&qd)[L], const float (&last_qd)[L], float (&tau)[L]) {
+#pragma unroll
+    for (int j = 0; j < L; j++) {
+        const float *tj = tab + j * LG_JS;
+        float a = act[j] * P.action_scale, t;
+        if (P.control_type == LG_CTRL_P) t = tj[J_KP] * (a + tj[J_Q0] - q[j]) - tj[J_KD] * qd[j];
+        else if (P.control_type == LG_CTRL_V) t = tj[J_KP] * (a - qd[j]) - tj[J_KD] * (qd[j] - last_qd[j]) / P.sim_dt;
+        else t = a;
+        tau[j] = fminf(fmaxf(t, -tj[J_TLIM]), tj[J_TLIM]);
+    }
+}
+
+// ------------------------------------------------------------------ commands / heights / reset values
+LG_DEV void resample_commands(const lg_params &P, int e, int64_t step, int purpose, float (&cmd)[4]) {   // :347-369
+    float u[4];
+    rand4(P.seed, e, step, purpose, 0, u);
+    cmd[0] = urange(P.cmd_lin_vel_x[0], P.cmd_lin_vel_x[1], u[0]);
+    cmd[1] = urange(P.cmd_lin_vel_y[0], P.cmd_lin_vel_y[1], u[1]);
+    if (P.heading_command) cmd[3] = urange(P.cmd_heading[0], P.cmd_heading[1], u[2]);
+    else cmd[2] = urange(P.cmd_ang_vel_yaw[0], P.cmd_ang_vel_yaw[1], u[2]);
+    float keep = (sqrtf(cmd[0] * cmd[0] + cmd[1] * cmd[1]) > 0.2f) ? 1.0f : 0.0f;
+    cmd[0] *= keep; cmd[1] *= keep;
+}
+LG_DEV float wrap_to_pi(float a) {                                                                       // utils/math.py:45-48
+    const float two_pi = 6.2831855f, pi = 3.14159274f;
+    a = fmodf(a, two_pi); if (a < 0.0f) a += two_pi;
+    if (a > pi) a -= two_pi;
+    return a;
+}
+LG_DEV float sample_height(const KArgs &A, const float *root, const float *qy, int i) {                  // :831-869, one point
+    const lg_params &P = A.P;
+    V3 p = quat_apply(qy, v3(P.height_points[i][0], P.height_points[i][1], 0.0f));
+    float px = p.x + root[0] + P.hf_border, py = p.y + root[1] + P.hf_border;
+    long ix = (long)(px / P.hf_horizontal_scale), iy = (long)(py / P.hf_horizontal_scale);
+    ix = ix < 0 ? 0 : ix; ix = ix > P.hf_rows - 2 ? P.hf_rows - 2 : ix;
+    iy = iy < 0 ? 0 : iy; iy = iy > P.hf_cols - 2 ? P.hf_cols - 2 : iy;
+    const int16_t *H = A.B.height_samples;
+    int16_t h1 = H[ix * P.hf_cols + iy], h2 = H[(ix + 1) * P.hf_cols + iy], h3 = H[ix * P.hf_cols + iy + 1];
+    int16_t h = h1 < h2 ? h1 : h2; h = h < h3 ? h : h3;
+    return (float)h * P.hf_vertical_scale;
+}
+
+// New state of a reset environment (reset_idx :147-191).  Every lane of the env computes the shared part
+// identically; `origin` is in/out (terrain curriculum :446-469), lane-0 writes are done by the caller.
+template <class T>
+LG_DEV void reset_values(const KArgs &A, const float *tab, int e, int k, int64_t step, float (&root)[13], float (&q)[T::L],
+                         float (&qd)[T::L], float (&cmd)[4], float (&origin)[3], int &level, bool &level_changed) {
+    constexpr int L = T::L;
+    const lg_params &P = A.P;
+    float u[4], v[4];
+    level_changed = false;
+    if (P.terrain_curriculum && A.B.terrain_levels) {
+        float dx = root[0] - origin[0], dy = root[1] - origin[1], dist = sqrtf(dx * dx + dy * dy);
+        int up = dist > P.terrain_env_length / 2;
+        int down = (dist < sqrtf(cmd[0] * cmd[0] + cmd[1] * cmd[1]) * P.max_episode_length_s * 0.5f) && !up;
+        int lvl = A.B.terrain_levels[e] + up - down;
+        if (lvl >= P.terrain_num_rows) {
+            rand4(P.seed, e, step, RNG_TERRAIN, 0, u);
+            lvl = (int)(u[0] * P.terrain_num_rows);
+            if (lvl >= P.terrain_num_rows) lvl = P.terrain_num_rows - 1;
+        } else if (lvl < 0) lvl = 0;
+        level = lvl; level_changed = true;
+        const float *to = A.B.terrain_origins + ((size_t)lvl * P.terrain_num_cols + A.B.terrain_types[e]) * 3;
+        origin[0] = to[0]; origin[1] = to[1]; origin[2] = to[2];
+    }
+#pragma unroll
+    for (int j = 0; j < L; j++) {
+        int d = k * L + j;
+        rand4(P.seed, e, step, RNG_DOF, d >> 2, u);
+        float uj = (d & 3) == 0 ? u[0] : ((d & 3) == 1 ? u[1] : ((d & 3) == 2 ? u[2] : u[3]));
+        q[j] = tab[j * LG_JS + J_Q0] * urange(0.5f, 1.5f, uj);
+        qd[j] = 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < 13; i++) root[i] = P.base_init_state[i];
+    root[0] += origin[0]; root[1] += origin[1]; root[2] += origin[2];
+    rand4(P.seed, e, step, RNG_ROOT, 0, u); rand4(P.seed, e, step, RNG_ROOT, 1, v);
+    if (P.custom_origins) { root[0] += urange(-1.0f, 1.0f, u[0]); root[1] += urange(-1.0f, 1.0f, u[1]); }
+    root[7] = urange(-0.5f, 0.5f, u[2]); root[8] = urange(-0.5f, 0.5f, u[3]);
+    root[9] = urange(-0.5f, 0.5f, v[0]); root[10] = urange(-0.5f, 0.5f, v[1]);
+    root[11] = urange(-0.5f, 0.5f, v[2]); root[12] = urange(-0.5f, 0.5f, v[3]);
+    resample_commands(P, e, step, RNG_CMD_RESET, cmd);
+}
+
+// ------------------------------------------------------------------ observations (legged_robot.py:212-230, :100-101)
+// lane k owns slots k*L..k*L+L-1 of each of the four 12-wide groups [base|dof_pos|dof_vel|actions]
+template <class T>
+LG_DEV void write_observations(const KArgs &A, int e, int k, bool live, const float *root, const float (&q)[T::L],
+                               const float (&qd)[T::L], const float (&act)[T::L], const float *tab, V3 blv, V3 bav, V3 pg,
+                               const float (&cmd)[4]) {
+    constexpr int K = T::K, L = T::L;
+    const lg_params &P = A.P;
+    float head[12] = {blv.x * P.obs_scale_lin_vel, blv.y * P.obs_scale_lin_vel, blv.z * P.obs_scale_lin_vel,
+                      bav.x * P.obs_scale_ang_vel, bav.y * P.obs_scale_ang_vel, bav.z * P.obs_scale_ang_vel,
+                      pg.x, pg.y, pg.z,
+                      cmd[0] * P.obs_scale_lin_vel, cmd[1] * P.obs_scale_lin_vel, cmd[2] * P.obs_scale_ang_vel};
+    float hnz[12] = {P.noise_lin_vel, P.noise_lin_vel, P.noise_lin_vel, P.noise_ang_vel, P.noise_ang_vel, P.noise_ang_vel,
+                     P.noise_gravity, P.noise_gravity, P.noise_gravity, 0.0f, 0.0f, 0.0f};
+    float val[4][L], nz[4][L];
+#pragma unroll
+    for (int j = 0; j < L; j++) {
+        float hv = head[j], hn = hnz[j];
+#pragma unroll
+        for (int kk = 1; kk < K; kk++) { hv = (k == kk) ? head[kk * L + j] : hv; hn = (k == kk) ? hnz[kk * L + j] : hn; }
+        val[0][j] = hv; nz[0][j] = hn;
+        val[1][j] = (q[j] - tab[j * LG_JS + J_Q0]) * P.obs_scale_dof_pos; nz[1][j] = P.noise_dof_pos;
+        val[2][j] = qd[j] * P.obs_scale_dof_vel; nz[2][j] = P.noise_dof_vel;
+        val[3][j] = act[j]; nz[3][j] = 0.0f;
+    }
+    float *obs = A.B.obs_buf + (size_t)e * P.num_obs;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        float u[4], u2[4];
+        if (P.add_noise) {
+            rand4(P.seed, e, A.step, RNG_NOISE, (g * K + k) * 2, u);
+            if (L > 4) rand4(P.seed, e, A.step, RNG_NOISE, (g * K + k) * 2 + 1, u2);
+        }
+#pragma unroll
+        for (int j = 0; j < L; j++) {
+            float o = val[g][j];
+            if (P.add_noise) {
+                float uj = (j < 4) ? u[j & 3] : u2[j & 3];
+                o += (2.0f * uj - 1.0f) * nz[g][j];
+            }
+            o = fminf(fmaxf(o, -P.clip_observations), P.clip_observations);
+            if (live) obs[g * 12 + k * L + j] = o;
+        }
+    }
+    if (P.measure_heights) {
+        const float *mh = A.B.measured_heights + (size_t)e * P.num_height_points;
+        const int nchunk = (P.num_height_points + 3) >> 2;
+        for (int c = k; c < nchunk; c += K) {          // chunk c = points 4c..4c+3, one Philox block each
+            float u[4] = {0, 0, 0, 0};
+            if (P.add_noise) rand4(P.seed, e, A.step, RNG_NOISE_H, c, u);
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                int i = 4 * c + t;
+                if (i < P.num_height_points) {
+                    float h = root[2] - 0.5f - mh[i];
+                    float o = fminf(fmaxf(h, -1.0f), 1.0f) * P.obs_scale_height;
+                    if (P.add_noise) o += (2.0f * u[t] - 1.0f) * P.noise_height;
+                    o = fminf(fmaxf(o, -P.clip_observations), P.clip_observations);
+                    if (live) obs[48 + i] = o;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ LDS staging helpers
+template <class T> LG_DEV void stage_limb_table(const KArgs &A, float *lds_tab) {
+    for (int i = threadIdx.x; i < T::K * Tab<T>::STRIDE; i += blockDim.x) lds_tab[i] = A.limb_table[i];
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------ THE fused policy-step kernel
+template <class T, bool NET, bool HF>
+__global__ void __launch_bounds__(LG_BLOCK) k_step(const KArgs A) {
+    constexpr int K = T::K, L = T::L, ND = K * L, NREP = T::NREP;
+    const lg_params &P = A.P;
+    const lg_buffers &B = A.B;
+    __shared__ float lds_tab[T::K * Tab<T>::STRIDE];
+    __shared__ float4 lds_lstm[NET ? L * 8 : 1][LG_BLOCK];      // [joint*8 + quarter(h0 lo,h0 hi,c0..,h1..,c1..)][lane]
+    stage_limb_table<T>(A, lds_tab);
+
+    const int N = P.num_envs;
+    const int tid = blockIdx.x * LG_BLOCK + threadIdx.x;
+    int e = tid / K;
+    const int k = tid % K;
+    const bool live = e < N;
+    if (!live) e = N - 1;
+    const float *tab = lds_tab + k * Tab<T>::STRIDE;
+    const int d0 = e * ND + k * L;                                // first dof of this lane
+
+    // ---- load persistent state (read once per env-step)
+    float root[13], q[L], qd[L], act[L], tau[L];
+#pragma unroll
+    for (int i = 0; i < 13; i++) root[i] = B.root_states[(size_t)e * 13 + i];
+#pragma unroll
+    for (int j = 0; j < L; j++) {
+        float2 s = reinterpret_cast<const float2 *>(B.dof_state)[d0 + j];
+        q[j] = s.x; qd[j] = s.y;
+        float a = A.actions_in[d0 + j];
+        act[j] = fminf(fmaxf(a, -P.clip_actions), P.clip_actions);       // :86-87
+        tau[j] = 0.0f;
+    }
+    const size_t plane = (size_t)N * ND;
+    if (NET) {
+#pragma unroll
+        for (int j = 0; j < L; j++) {
+            const float4 *h0 = reinterpret_cast<const float4 *>(B.sea_hidden_state + (size_t)(d0 + j) * 8);
+            const float4 *c0 = reinterpret_cast<const float4 *>(B.sea_cell_state + (size_t)(d0 + j) * 8);
+            const float4 *h1 = reinterpret_cast<const float4 *>(B.sea_hidden_state + (plane + d0 + j) * 8);
+            const float4 *c1 = reinterpret_cast<const float4 *>(B.sea_cell_state + (plane + d0 + j) * 8);
+            lds_lstm[j * 8 + 0][threadIdx.x] = h0[0]; lds_lstm[j * 8 + 1][threadIdx.x] = h0[1];
+            lds_lstm[j * 8 + 2][threadIdx.x] = c0[0]; lds_lstm[j * 8 + 3][threadIdx.x] = c0[1];
+            lds_lstm[j * 8 + 4][threadIdx.x] = h1[0]; lds_lstm[j * 8 + 5][threadIdx.x] = h1[1];
+            lds_lstm[j * 8 + 6][threadIdx.x] = c1[0]; lds_lstm[j * 8 + 7][threadIdx.x] = c1[1];
+        }
+    }
+    const float mu = 0.5f * ((B.friction_coeffs ? B.friction_coeffs[e] : 1.0f) + P.ground_friction);
+    const float base_mass = A.base.mass + (B.base_mass_delta ? B.base_mass_delta[e] : 0.0f);
+    float last_qd[L];
+#pragma unroll
+    for (int j = 0; j < L; j++) last_qd[j] = B.last_dof_vel[d0 + j];
+
+    // ---- decimation x (torque -> physics)   legged_robot.py:90-96
+    float Frep[NREP][3], Fbase[3];
+#pragma unroll 1
+    for (int it = 0; it < P.decimation; it++) {
+        if (NET) {
+            cfp W = (cfp)(uintptr_t)A.weights;
+#pragma unroll 1
+            for (int j = 0; j < L; j++) {
+                LstmState s;
+                float4 t;
+#define LD(dst, slot) t = lds_lstm[j * 8 + slot][threadIdx.x]; dst[0] = t.x; dst[1] = t.y; dst[2] = t.z; dst[3] = t.w;
+                LD(s.h0, 0) LD((s.h0 + 4), 1) LD(s.c0, 2) LD((s.c0 + 4), 3) LD(s.h1, 4) LD((s.h1 + 4), 5) LD(s.c1, 6) LD((s.c1 + 4), 7)
+#undef LD
+                float qj = 0, qdj = 0, aj = 0, q0j = tab[j * LG_JS + J_Q0];
+#pragma unroll
+                for (int jj = 0; jj < L; jj++) if (jj == j) { qj = q[jj]; qdj = qd[jj]; aj = act[jj]; }
+                float t_out = actuator_row(W, aj * P.action_scale + q0j - qj, qdj, s);
+#pragma unroll
+                for (int jj = 0; jj < L; jj++) if (jj == j) tau[jj] = t_out;
+#define ST(src, slot) lds_lstm[j * 8 + slot][threadIdx.x] = make_float4(src[0], src[1], src[2], src[3]);
+                ST(s.h0, 0) ST((s.h0 + 4), 1) ST(s.c0, 2) ST((s.c0 + 4), 3) ST(s.h1, 4) ST((s.h1 + 4), 5) ST(s.c1, 6) ST((s.c1 + 4), 7)
+#undef ST
+            }
+        } else {
+            pd_torques<L>(P, tab, act, q, qd, last_qd, tau);
+        }
+        physics_substep<T, HF>(A, tab, root, q, qd, tau, base_mass, mu, Frep, Fbase);
+    }
+
+    // =====================  post_physics_step  (legged_robot.py:106-137)  =====================
+    int64_t ep_len = B.episode_length_buf[e] + 1;                                   // :114
+    V3 blv = quat_rotate_inverse(root + 3, v3(root[7], root[8], root[9]));          // :118-121
+    V3 bav = quat_rotate_inverse(root + 3, v3(root[10], root[11], root[12]));
+    V3 pg = quat_rotate_inverse(root + 3, v3(0, 0, -1));
+    float cmd[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) cmd[i] = B.commands[(size_t)e * 4 + i];
+    // _post_physics_step_callback :329-345
+    if (ep_len % P.resample_interval == 0) resample_commands(P, e, A.step, RNG_CMD_STEP, cmd);
+    if (P.heading_command) {
+        V3 fwd = quat_apply(root + 3, v3(1, 0, 0));
+        float heading = atan2f(fwd.y, fwd.x);
+        cmd[2] = fminf(fmaxf(0.5f * wrap_to_pi(cmd[3] - heading), -1.0f), 1.0f);
+    }
+    float hsum = 0.0f;                                                              // _get_heights :831-869
+    if (P.measure_heights) {
+        // lane k samples (and later consumes, in the observation) the points of chunks c = k, k+K, ...:
+        // no other lane ever reads what this lane writes, so no barrier is needed.
+        float qy[4] = {0, 0, root[5], root[6]};
+        float nrm = fmaxf(sqrtf(qy[2] * qy[2] + qy[3] * qy[3]), 1e-9f);
+        qy[2] /= nrm; qy[3] /= nrm;
+        float *mh = B.measured_heights + (size_t)e * P.num_height_points;
+        const int nchunk = (P.num_height_points + 3) >> 2;
+        for (int c = k; c < nchunk; c += K)
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                int i = 4 * c + t;
+                if (i < P.num_height_points) {
+                    float h = HF ? sample_height(A, root, qy, i) : 0.0f;
+                    if (live) mh[i] = h;
+                    hsum += root[2] - h;
+                }
+            }
+    }
+    if (P.push_interval > 0 && A.step % P.push_interval == 0) {                     // _push_robots :438-444
+        float u[4];
+        rand4(P.seed, e, A.step, RNG_PUSH, 0, u);
+        root[7] = urange(-P.max_push_vel, P.max_push_vel, u[0]);
+        root[8] = urange(-P.max_push_vel, P.max_push_vel, u[1]);
+    }
+
+    // contact_forces (net contact force tensor, last sub-step) -- also the inputs of termination / rewards
+    const int rep0 = 1 + k * NREP;
+    if (live) {
+        float *cf = B.contact_forces + ((size_t)e * (1 + K * NREP) + rep0) * 3;
+#pragma unroll
+        for (int r = 0; r < NREP; r++) { cf[3 * r] = Frep[r][0]; cf[3 * r + 1] = Frep[r][1]; cf[3 * r + 2] = Frep[r][2]; }
+        if (k == 0) { float *c0 = B.contact_forces + (size_t)e * (1 + K * NREP) * 3; c0[0] = Fbase[0]; c0[1] = Fbase[1]; c0[2] = Fbase[2]; }
+    }
+    // check_termination :139-145
+    int term_local = 0;
+    float coll_local = 0.0f;
+#pragma unroll
+    for (int r = 0; r < NREP; r++) {
+        float n = sqrtf(Frep[r][0] * Frep[r][0] + Frep[r][1] * Frep[r][1] + Frep[r][2] * Frep[r][2]);
+        if ((A.termination_mask >> (rep0 + r)) & 1u) term_local |= (n > 1.0f);
+        if ((A.penalised_mask >> (rep0 + r)) & 1u) coll_local += (n > 0.1f) ? 1.0f : 0.0f;
+    }
+    float nbase = sqrtf(Fbase[0] * Fbase[0] + Fbase[1] * Fbase[1] + Fbase[2] * Fbase[2]);
+    int contact_term = group_or<K>(term_local);
+    if (A.termination_mask & 1u) contact_term |= (nbase > 1.0f);
+    float coll = group_sum<K>(coll_local);
+    if (A.penalised_mask & 1u) coll += (nbase > 0.1f) ? 1.0f : 0.0f;
+    const bool time_out = ep_len > P.max_episode_length;
+    const bool reset = contact_term || time_out;
+
+    // compute_reward :193-210 ; terms :872-969, cassie.py:43-46
+    float last_act[L];
+#pragma unroll
+    for (int j = 0; j < L; j++) last_act[j] = B.last_actions[d0 + j];
+    float s_ar = 0, s_acc = 0, s_lim = 0, s_dv = 0, s_dvl = 0, s_tl = 0, s_tq = 0, s_ss = 0;
+#pragma unroll
+    for (int j = 0; j < L; j++) {
+        const float *tj = tab + j * LG_JS;
+        float da = last_act[j] - act[j]; s_ar += da * da;
+        float dd = (last_qd[j] - qd[j]) / P.dt_policy; s_acc += dd * dd;
+        float ol = -fminf(q[j] - tj[J_SLO], 0.0f); ol += fmaxf(q[j] - tj[J_SHI], 0.0f); s_lim += ol;
+        s_dv += qd[j] * qd[j];
+        s_dvl += fminf(fmaxf(fabsf(qd[j]) - tj[J_DVL] * P.soft_dof_vel_limit, 0.0f), 1.0f);
+        s_tl += fmaxf(fabsf(tau[j]) - tj[J_TLIM] * P.soft_torque_limit, 0.0f);
+        s_tq += tau[j] * tau[j];
+        s_ss += fabsf(q[j] - tj[J_Q0]);
+    }
+    s_ar = group_sum<K>(s_ar); s_acc = group_sum<K>(s_acc); s_lim = group_sum<K>(s_lim); s_dv = group_sum<K>(s_dv);
+    s_dvl = group_sum<K>(s_dvl); s_tl = group_sum<K>(s_tl); s_tq = group_sum<K>(s_tq); s_ss = group_sum<K>(s_ss);
+    const float *ff = Frep[T::FOOT_REP];
+    const float cmd_xy = sqrtf(cmd[0] * cmd[0] + cmd[1] * cmd[1]);
+    float fnorm = sqrtf(ff[0] * ff[0] + ff[1] * ff[1] + ff[2] * ff[2]);
+    float fcf = group_sum<K>(fmaxf(fnorm - P.max_contact_force, 0.0f));
+    int stumble = group_or<K>(sqrtf(ff[0] * ff[0] + ff[1] * ff[1]) > 5.0f * fabsf(ff[2]) ? 1 : 0);
+    float nfly = group_sum<K>(ff[2] > 0.1f ? 1.0f : 0.0f);
+    float air = 0.0f;
+    float fat = B.feet_air_time[(size_t)e * K + k];
+    uint8_t lc = B.last_contacts[(size_t)e * K + k];
+    if (P.reward_scale[LG_REW_FEET_AIR_TIME] != 0.0f) {
+        bool contact = ff[2] > 1.0f, filt = contact || lc;
+        lc = (uint8_t)contact;
+        bool first = (fat > 0.0f) && filt;
+        fat += P.dt_policy;
+        air = (fat - 0.5f) * (first ? 1.0f : 0.0f);
+        fat *= filt ? 0.0f : 1.0f;
+        air = group_sum<K>(air) * ((cmd_xy > 0.1f) ? 1.0f : 0.0f);
+    }
+    const float base_h = P.measure_heights ? group_sum<K>(hsum) / (float)P.num_height_points : root[2];
+    float term[LG_NUM_REWARD_TERMS];
+    term[LG_REW_ACTION_RATE] = s_ar;
+    term[LG_REW_ANG_VEL_XY] = bav.x * bav.x + bav.y * bav.y;
+    term[LG_REW_BASE_HEIGHT] = (base_h - P.base_height_target) * (base_h - P.base_height_target);
+    term[LG_REW_COLLISION] = coll;
+    term[LG_REW_DOF_ACC] = s_acc;
+    term[LG_REW_DOF_POS_LIMITS] = s_lim;
+    term[LG_REW_DOF_VEL] = s_dv;
+    term[LG_REW_DOF_VEL_LIMITS] = s_dvl;
+    term[LG_REW_FEET_AIR_TIME] = air;
+    term[LG_REW_FEET_CONTACT_FORCES] = fcf;
+    term[LG_REW_LIN_VEL_Z] = blv.z * blv.z;
+    term[LG_REW_NO_FLY] = (nfly == 1.0f) ? 1.0f : 0.0f;
+    term[LG_REW_ORIENTATION] = pg.x * pg.x + pg.y * pg.y;
+    term[LG_REW_STAND_STILL] = s_ss * ((cmd_xy < 0.1f) ? 1.0f : 0.0f);
+    term[LG_REW_STUMBLE] = stumble ? 1.0f : 0.0f;
+    term[LG_REW_TERMINATION] = (reset && !time_out) ? 1.0f : 0.0f;
+    term[LG_REW_TORQUE_LIMITS] = s_tl;
+    term[LG_REW_TORQUES] = s_tq;
+    {
+        float ex = cmd[0] - blv.x, ey = cmd[1] - blv.y, ew = cmd[2] - bav.z;
+        term[LG_REW_TRACKING_LIN_VEL] = __expf(-(ex * ex + ey * ey) / P.tracking_sigma);
+        term[LG_REW_TRACKING_ANG_VEL] = __expf(-(ew * ew) / P.tracking_sigma);
+    }
+    float rew = 0.0f;
+    const bool writer = live && k == 0;
+#pragma unroll
+    for (int t = 0; t < LG_NUM_REWARD_TERMS; t++) {
+        if (t == LG_REW_TERMINATION) continue;
+        const int slot = P.reward_slot[t];
+        if (slot < 0) continue;
+        float r = term[t] * P.reward_scale[t];
+        rew += r;
+        if (writer) {
+            float *es = B.episode_sums + (size_t)slot * N + e;
+            float sum = *es + r;
+            *es = reset ? 0.0f : sum;
+            B.episode_sums_done[(size_t)slot * N + e] = reset ? sum : 0.0f;
+        }
+    }
+    if (P.only_positive_rewards) rew = fmaxf(rew, 0.0f);
+    if (P.reward_slot[LG_REW_TERMINATION] >= 0) {
+        const int slot = P.reward_slot[LG_REW_TERMINATION];
+        float r = term[LG_REW_TERMINATION] * P.reward_scale[LG_REW_TERMINATION];
+        rew += r;
+        if (writer) {
+            float *es = B.episode_sums + (size_t)slot * N + e;
+            float sum = *es + r;
+            *es = reset ? 0.0f : sum;
+            B.episode_sums_done[(size_t)slot * N + e] = reset ? sum : 0.0f;
+        }
+    }
+
+    // reset_idx for terminated envs (predicated epilogue) :128-129, anymal.py:56-60
+    float origin[3] = {B.env_origins[(size_t)e * 3], B.env_origins[(size_t)e * 3 + 1], B.env_origins[(size_t)e * 3 + 2]};
+    if (reset) {
+        int level = 0; bool level_changed = false;
+        reset_values<T>(A, tab, e, k, A.step, root, q, qd, cmd, origin, level, level_changed);
+        if (writer && level_changed) {
+            B.terrain_levels[e] = level;
+            B.env_origins[(size_t)e * 3] = origin[0]; B.env_origins[(size_t)e * 3 + 1] = origin[1]; B.env_origins[(size_t)e * 3 + 2] = origin[2];
+        }
+        fat = 0.0f; ep_len = 0;
+        if (NET) {
+#pragma unroll
+            for (int s = 0; s < L * 8; s++) lds_lstm[s][threadIdx.x] = make_float4(0, 0, 0, 0);
+        }
+    }
+
+    // compute_observations :130 (stale base-frame quantities for reset envs, as in the reference)
+    write_observations<T>(A, e, k, live, root, q, qd, act, tab, blv, bav, pg, cmd);
+
+    // ---- write persistent state back (written once per env-step)
+    if (live) {
+#pragma unroll
+        for (int j = 0; j < L; j++) {
+            reinterpret_cast<float2 *>(B.dof_state)[d0 + j] = make_float2(q[j], qd[j]);
+            B.actions[d0 + j] = act[j];
+            B.torques[d0 + j] = tau[j];
+            B.last_actions[d0 + j] = act[j];                      // :132 (after the reset zeroing, as in the reference)
+            B.last_dof_vel[d0 + j] = qd[j];                       // :133
+        }
+        B.feet_air_time[(size_t)e * K + k] = fat;
+        B.last_contacts[(size_t)e * K + k] = lc;
+        if (NET) {
+#pragma unroll
+            for (int j = 0; j < L; j++) {
+                float4 *h0 = reinterpret_cast<float4 *>(B.sea_hidden_state + (size_t)(d0 + j) * 8);
+                float4 *c0 = reinterpret_cast<float4 *>(B.sea_cell_state + (size_t)(d0 + j) * 8);
+                float4 *h1 = reinterpret_cast<float4 *>(B.sea_hidden_state + (plane + d0 + j) * 8);
+                float4 *c1 = reinterpret_cast<float4 *>(B.sea_cell_state + (plane + d0 + j) * 8);
+                h0[0] = lds_lstm[j * 8 + 0][threadIdx.x]; h0[1] = lds_lstm[j * 8 + 1][threadIdx.x];
+                c0[0] = lds_lstm[j * 8 + 2][threadIdx.x]; c0[1] = lds_lstm[j * 8 + 3][threadIdx.x];
+                h1[0] = lds_lstm[j * 8 + 4][threadIdx.x]; h1[1] = lds_lstm[j * 8 + 5][threadIdx.x];
+                c1[0] = lds_lstm[j * 8 + 6][threadIdx.x]; c1[1] = lds_lstm[j * 8 + 7][threadIdx.x];
+            }
+        }
+        if (k == 0) {
+#pragma unroll
+            for (int i = 0; i < 13; i++) B.root_states[(size_t)e * 13 + i] = root[i];
+#pragma unroll
+            for (int i = 0; i < 6; i++) B.last_root_vel[(size_t)e * 6 + i] = root[7 + i];     // :134
+#pragma unroll
+            for (int i = 0; i < 4; i++) B.commands[(size_t)e * 4 + i] = cmd[i];
+            B.base_lin_vel[(size_t)e * 3] = blv.x; B.base_lin_vel[(size_t)e * 3 + 1] = blv.y; B.base_lin_vel[(size_t)e * 3 + 2] = blv.z;
+            B.base_ang_vel[(size_t)e * 3] = bav.x; B.base_ang_vel[(size_t)e * 3 + 1] = bav.y; B.base_ang_vel[(size_t)e * 3 + 2] = bav.z;
+            B.projected_gravity[(size_t)e * 3] = pg.x; B.projected_gravity[(size_t)e * 3 + 1] = pg.y; B.projected_gravity[(size_t)e * 3 + 2] = pg.z;
+            B.rew_buf[e] = rew;
+            B.reset_buf[e] = (uint8_t)reset;
+            B.time_out_buf[e] = (uint8_t)time_out;
+            B.episode_length_buf[e] = ep_len;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ reset_idx on an id list (base_task.py:114-118)
+template <class T, bool NET>
+__global__ void __launch_bounds__(LG_BLOCK) k_reset(const KArgs A) {
+    constexpr int K = T::K, L = T::L, ND = K * L;
+    const lg_params &P = A.P;
+    const lg_buffers &B = A.B;
+    __shared__ float lds_tab[T::K * Tab<T>::STRIDE];
+    stage_limb_table<T>(A, lds_tab);
+    const int tid = blockIdx.x * LG_BLOCK + threadIdx.x;
+    const int idx = tid / K, k = tid % K;
+    if (idx >= A.count) return;
+    const int e = A.env_ids[idx];
+    const int N = P.num_envs;
+    const float *tab = lds_tab + k * Tab<T>::STRIDE;
+    const int d0 = e * ND + k * L;
+    float root[13], q[L], qd[L], cmd[4], origin[3];
+#pragma unroll
+    for (int i = 0; i < 13; i++) root[i] = B.root_states[(size_t)e * 13 + i];
+#pragma unroll
+    for (int i = 0; i < 4; i++) cmd[i] = B.commands[(size_t)e * 4 + i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) origin[i] = B.env_origins[(size_t)e * 3 + i];
+    int level = 0; bool level_changed = false;
+    reset_values<T>(A, tab, e, k, A.step, root, q, qd, cmd, origin, level, level_changed);
+#pragma unroll
+    for (int j = 0; j < L; j++) {
+        reinterpret_cast<float2 *>(B.dof_state)[d0 + j] = make_float2(q[j], qd[j]);
+        B.last_actions[d0 + j] = 0.0f;
+        B.last_dof_vel[d0 + j] = 0.0f;
+    }
+    B.feet_air_time[(size_t)e * K + k] = 0.0f;
+    if (NET) {
+        const size_t plane = (size_t)N * ND;
+#pragma unroll
+        for (int j = 0; j < L; j++)
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                B.sea_hidden_state[(size_t)(d0 + j) * 8 + u] = 0.0f; B.sea_cell_state[(size_t)(d0 + j) * 8 + u] = 0.0f;
+                B.sea_hidden_state[(plane + d0 + j) * 8 + u] = 0.0f; B.sea_cell_state[(plane + d0 + j) * 8 + u] = 0.0f;
+            }
+    }
+    if (k == 0) {
+#pragma unroll
+        for (int i = 0; i < 13; i++) B.root_states[(size_t)e * 13 + i] = root[i];
+#pragma unroll
+        for (int i = 0; i < 4; i++) B.commands[(size_t)e * 4 + i] = cmd[i];
+        if (level_changed) {
+            B.terrain_levels[e] = level;
+#pragma unroll
+            for (int i = 0; i < 3; i++) B.env_origins[(size_t)e * 3 + i] = origin[i];
+        }
+        B.episode_length_buf[e] = 0;
+        B.reset_buf[e] = 1;
+        for (int t = 0; t < P.num_reward_slots; t++) {
+            B.episode_sums_done[(size_t)t * N + e] = B.episode_sums[(size_t)t * N + e];
+            B.episode_sums[(size_t)t * N + e] = 0.0f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ sub-path kernels (parity tests drive these)
+__global__ void __launch_bounds__(256) k_actuator(const float *weights, const float *pos_err, const float *vel, float *torques,
+                                                   float *hidden, float *cell, int rows) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    cfp W = (cfp)(uintptr_t)weights;
+    LstmState s;
+    float *h0 = hidden + (size_t)r * 8, *c0 = cell + (size_t)r * 8, *h1 = hidden + ((size_t)rows + r) * 8, *c1 = cell + ((size_t)rows + r) * 8;
+#pragma unroll
+    for (int u = 0; u < 8; u++) { s.h0[u] = h0[u]; s.c0[u] = c0[u]; s.h1[u] = h1[u]; s.c1[u] = c1[u]; }
+    torques[r] = actuator_row(W, pos_err[r], vel[r], s);
+#pragma unroll
+    for (int u = 0; u < 8; u++) { h0[u] = s.h0[u]; c0[u] = s.c0[u]; h1[u] = s.h1[u]; c1[u] = s.c1[u]; }
+}
+
+template <class T, bool HF>
+__global__ void __launch_bounds__(LG_BLOCK) k_physics(const KArgs A, const float *torques, int write_contacts) {
+    constexpr int K = T::K, L = T::L, ND = K * L, NREP = T::NREP;
+    const lg_buffers &B = A.B;
+    __shared__ float lds_tab[T::K * Tab<T>::STRIDE];
+    stage_limb_table<T>(A, lds_tab);
+    const int N = A.P.num_envs;
+    const int tid = blockIdx.x * LG_BLOCK + threadIdx.x;
+    int e = tid / K;
+    const int k = tid % K;
+    const bool live = e < N;
+    if (!live) e = N - 1;
+    const float *tab = lds_tab + k * Tab<T>::STRIDE;
+    const int d0 = e * ND + k * L;
+    float root[13], q[L], qd[L], tau[L], Frep[NREP][3], Fbase[3];
+#pragma unroll
+    for (int i = 0; i < 13; i++) root[i] = B.root_states[(size_t)e * 13 + i];
+#pragma unroll
+    for (int j = 0; j < L; j++) { q[j] = B.dof_state[2 * (d0 + j)]; qd[j] = B.dof_state[2 * (d0 + j) + 1]; tau[j] = torques[d0 + j]; }
+    const float mu = 0.5f * ((B.friction_coeffs ? B.friction_coeffs[e] : 1.0f) + A.P.ground_friction);
+    const float base_mass = A.base.mass + (B.base_mass_delta ? B.base_mass_delta[e] : 0.0f);
+    physics_substep<T, HF>(A, tab, root, q, qd, tau, base_mass, mu, Frep, Fbase);
+    if (!live) return;
+#pragma unroll
+    for (int j = 0; j < L; j++) { B.dof_state[2 * (d0 + j)] = q[j]; B.dof_state[2 * (d0 + j) + 1] = qd[j]; }
+    if (write_contacts) {
+        float *cf = B.contact_forces + ((size_t)e * (1 + K * NREP) + 1 + k * NREP) * 3;
+#pragma unroll
+        for (int r = 0; r < NREP; r++) { cf[3 * r] = Frep[r][0]; cf[3 * r + 1] = Frep[r][1]; cf[3 * r + 2] = Frep[r][2]; }
+    }
+    if (k == 0) {
+#pragma unroll
+        for (int i = 0; i < 13; i++) B.root_states[(size_t)e * 13 + i] = root[i];
+        if (write_contacts) { float *c0 = B.contact_forces + (size_t)e * (1 + K * NREP) * 3; c0[0] = Fbase[0]; c0[1] = Fbase[1]; c0[2] = Fbase[2]; }
+    }
+}
+
+template <class T>
+__global__ void __launch_bounds__(LG_BLOCK) k_obs(const KArgs A) {
+    constexpr int K = T::K, L = T::L, ND = K * L;
+    const lg_buffers &B = A.B;
+    __shared__ float lds_tab[T::K * Tab<T>::STRIDE];
+    stage_limb_table<T>(A, lds_tab);
+    const int N = A.P.num_envs;
+    const int tid = blockIdx.x * LG_BLOCK + threadIdx.x;
+    int e = tid / K;
+    const int k = tid % K;
+    const bool live = e < N;
+    if (!live) e = N - 1;
+    const float *tab = lds_tab + k * Tab<T>::STRIDE;
+    const int d0 = e * ND + k * L;
+    float root[13], q[L], qd[L], act[L], cmd[4];
+#pragma unroll
+    for (int i = 0; i < 13; i++) root[i] = B.root_states[(size_t)e * 13 + i];
+#pragma unroll
+    for (int j = 0; j < L; j++) { q[j] = B.dof_state[2 * (d0 + j)]; qd[j] = B.dof_state[2 * (d0 + j) + 1]; act[j] = B.actions[d0 + j]; }
+#pragma unroll
+    for (int i = 0; i < 4; i++) cmd[i] = B.commands[(size_t)e * 4 + i];
+    V3 blv = v3(B.base_lin_vel[(size_t)e * 3], B.base_lin_vel[(size_t)e * 3 + 1], B.base_lin_vel[(size_t)e * 3 + 2]);
+    V3 bav = v3(B.base_ang_vel[(size_t)e * 3], B.base_ang_vel[(size_t)e * 3 + 1], B.base_ang_vel[(size_t)e * 3 + 2]);
+    V3 pg = v3(B.projected_gravity[(size_t)e * 3], B.projected_gravity[(size_t)e * 3 + 1], B.projected_gravity[(size_t)e * 3 + 2]);
+    write_observations<T>(A, e, k, live, root, q, qd, act, tab, blv, bav, pg, cmd);
+}
+
+// ====================================================================  host side: C-ABI  ====================================================================
+static thread_local char g_err[512] = "";
+static int fail(int code, const char *fmt, const char *arg = "") { snprintf(g_err, sizeof g_err, fmt, arg); return code; }
+#define HIP_TRY(x) do { hipError_t _e = (x); if (_e != hipSuccess) return fail(-10, "HIP error: %s", hipGetErrorString(_e)); } while (0)
+
+enum RobotKind { ROBOT_ANYMAL = 0, ROBOT_CASSIE = 1 };
+
+struct lg_sim {
+    lg_params      P;
+    lg_robot_model M;
+    lg_buffers     B;
+    BaseTab        base;
+    RobotKind      kind;
+    int            device;
+    bool           has_net, bound;
+    float         *d_limb_table;
+    float         *d_weights;
+};
+
+template <class T> static int check_topology(const lg_robot_model *m) {
+    if (m->num_limbs != T::K || m->chain_len != T::L) return 0;
+    if (m->num_bodies != 1 + T::K * T::NREP || m->num_base_points != T::NBASE) return 0;
+    for (int i = 0; i < m->num_base_points; i++) if (m->base_points[i].report_body != 0) return 0;
+    for (int k = 0; k < T::K; k++) {
+        if (m->num_limb_points[k] != T::NPT) return 0;
+        for (int i = 0; i < T::NPT; i++) {
+            if (m->limb_points[k][i].joint != T::pt_joint(i)) return 0;
+            if (m->limb_points[k][i].report_body != 1 + k * T::NREP + T::pt_rep(i)) return 0;
+        }
+        if (m->foot_body[k] != 1 + k * T::NREP + T::FOOT_REP) return 0;
+    }
+    return 1;
+}
+
+template <class T> static void fill_limb_table(const lg_params &P, const lg_robot_model &M, float *t) {
+    memset(t, 0, sizeof(float) * T::K * Tab<T>::STRIDE);
+    for (int k = 0; k < T::K; k++) {
+        float *tk = t + k * Tab<T>::STRIDE;
+        for (int j = 0; j < T::L; j++) {
+            int d = k * T::L + j;
+            float *tj = tk + j * LG_JS;
+            memcpy(tj + J_POS, M.joint_pos[d], 12); memcpy(tj + J_ROT, M.joint_rot[d], 36); memcpy(tj + J_AXIS, M.joint_axis[d], 12);
+            tj[J_MASS] = M.body_mass[d]; memcpy(tj + J_COM, M.body_com[d], 12); memcpy(tj + J_INERTIA, M.body_inertia[d], 24);
+            tj[J_LO] = M.dof_lower[d]; tj[J_HI] = M.dof_upper[d]; tj[J_VLIM] = M.dof_vel_limit[d];
+            tj[J_ARM] = M.dof_armature[d]; tj[J_DAMP] = M.dof_damping[d];
+            tj[J_KP] = P.p_gains[d]; tj[J_KD] = P.d_gains[d]; tj[J_Q0] = P.default_dof_pos[d]; tj[J_TLIM] = P.torque_limits[d];
+            tj[J_SLO] = P.soft_pos_lower[d]; tj[J_SHI] = P.soft_pos_upper[d]; tj[J_DVL] = P.dof_vel_limits[d];
+        }
+        for (int i = 0; i < T::NPT; i++) {
+            float *tp = tk + T::L * LG_JS + 4 * i;
+            memcpy(tp, M.limb_points[k][i].pos, 12); tp[3] = M.limb_points[k][i].radius;
+        }
+    }
+}
+
+static int upload_tables(lg_sim *s) {
+    float host[LG_MAX_LIMBS * (LG_MAX_CHAIN * LG_JS + 4 * LG_MAX_LIMB_POINTS + 1)];
+    size_t n;
+    if (s->kind == ROBOT_ANYMAL) { fill_limb_table<AnymalTraits>(s->P, s->M, host); n = AnymalTraits::K * Tab<AnymalTraits>::STRIDE; }
+    else { fill_limb_table<CassieTraits>(s->P, s->M, host); n = CassieTraits::K * Tab<CassieTraits>::STRIDE; }
+    HIP_TRY(hipMemcpy(s->d_limb_table, host, n * sizeof(float), hipMemcpyHostToDevice));
+    s->base.mass = s->M.base_mass;
+    memcpy(s->base.com, s->M.base_com, 12); memcpy(s->base.inertia, s->M.base_inertia, 24);
+    memset(s->base.pts, 0, sizeof s->base.pts);
+    for (int i = 0; i < s->M.num_base_points; i++) { memcpy(s->base.pts[i], s->M.base_points[i].pos, 12); s->base.pts[i][3] = s->M.base_points[i].radius; }
+    return 0;
+}
+
+static void fill_args(const lg_sim *s, KArgs &a, int64_t step) {
+    a.P = s->P; a.B = s->B; a.base = s->base; a.limb_table = s->d_limb_table; a.weights = s->d_weights;
+    a.actions_in = nullptr; a.env_ids = nullptr; a.count = 0; a.step = step;
+    a.penalised_mask = s->M.penalised_mask; a.termination_mask = s->M.termination_mask;
+}
+template <class T> static int grid_for(int n_env_like) { return (n_env_like * T::K + LG_BLOCK - 1) / LG_BLOCK; }
+
+extern "C" {
+
+const char *lg_last_error(void) { return g_err; }
+int lg_abi_version(void) { return LG_ABI_VERSION; }
+int lg_sizeof(int which) {
+    switch (which) { case 0: return (int)sizeof(lg_params); case 1: return (int)sizeof(lg_robot_model);
+                     case 2: return (int)sizeof(lg_buffers); case 3: return (int)sizeof(lg_point); default: return -1; }
+}
+
+int lg_create(const lg_params *params, const lg_robot_model *model, const float *actuator_weights, int device_id, lg_sim **out) {
+    if (!params || !model || !out) return fail(-1, "null argument");
+    if (params->abi_version != LG_ABI_VERSION) return fail(-3, "ABI version mismatch");
+    static_assert(sizeof(KArgs) <= 4096, "kernel arguments must fit the 4 KiB kernarg segment");
+    RobotKind kind;
+    if (check_topology<AnymalTraits>(model)) kind = ROBOT_ANYMAL;
+    else if (check_topology<CassieTraits>(model)) kind = ROBOT_CASSIE;
+    else return fail(-4, "robot topology is not one of the compiled-in layouts (ANYmal-C 4x3, Cassie 2x6)");
+    if (params->control_type == LG_CTRL_ACTUATOR_NET && !actuator_weights) return fail(-2, "actuator-net control without weights");
+    if (params->control_type == LG_CTRL_ACTUATOR_NET && kind != ROBOT_ANYMAL) return fail(-2, "actuator net is compiled for the ANYmal layout only");
+    HIP_TRY(hipSetDevice(device_id));
+    lg_sim *s = new (std::nothrow) lg_sim();
+    if (!s) return fail(-5, "out of host memory");
+    s->P = *params; s->M = *model; s->kind = kind; s->device = device_id; s->bound = false;
+    s->has_net = actuator_weights != nullptr; s->d_weights = nullptr; s->d_limb_table = nullptr;
+    memset(&s->B, 0, sizeof s->B);
+    if (hipMalloc(&s->d_limb_table, sizeof(float) * LG_MAX_LIMBS * (LG_MAX_CHAIN * LG_JS + 4 * LG_MAX_LIMB_POINTS + 1)) != hipSuccess) { delete s; return fail(-10, "hipMalloc failed"); }
+    if (s->has_net) {
+        if (hipMalloc(&s->d_weights, sizeof(float) * LG_ACTUATOR_FLOATS) != hipSuccess) { (void)hipFree(s->d_limb_table); delete s; return fail(-10, "hipMalloc failed"); }
+        if (hipMemcpy(s->d_weights, actuator_weights, sizeof(float) * LG_ACTUATOR_FLOATS, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(s->d_weights); (void)hipFree(s->d_limb_table); delete s; return fail(-10, "hipMemcpy failed"); }
+    }
+    int rc = upload_tables(s);
+    if (rc) { lg_destroy(s); return rc; }
+    *out = s;
+    return 0;
+}
+
+void lg_destroy(lg_sim *s) {
+    if (!s) return;
+    if (s->d_limb_table) (void)hipFree(s->d_limb_table);
+    if (s->d_weights) (void)hipFree(s->d_weights);
+    delete s;
+}
+
+int lg_bind(lg_sim *s, const lg_buffers *b) {
+    if (!s || !b) return fail(-1, "null argument");
+    const void *need[] = {b->root_states, b->dof_state, b->contact_forces, b->obs_buf, b->rew_buf, b->reset_buf, b->time_out_buf,
+                          b->episode_length_buf, b->torques, b->actions, b->last_actions, b->last_dof_vel, b->last_root_vel, b->commands,
+                          b->feet_air_time, b->last_contacts, b->base_lin_vel, b->base_ang_vel, b->projected_gravity, b->episode_sums,
+                          b->episode_sums_done, b->env_origins};
+    for (size_t i = 0; i < sizeof need / sizeof *need; i++) if (!need[i]) return fail(-6, "a required buffer pointer is null");
+    if (s->P.control_type == LG_CTRL_ACTUATOR_NET && (!b->sea_hidden_state || !b->sea_cell_state)) return fail(-6, "actuator state buffers missing");
+    if (s->P.measure_heights && !b->measured_heights) return fail(-6, "measured_heights buffer missing");
+    if (s->P.terrain_type == LG_TERRAIN_HEIGHTFIELD && !b->height_samples) return fail(-6, "height_samples missing");
+    if (s->P.terrain_curriculum && (!b->terrain_levels || !b->terrain_types || !b->terrain_origins)) return fail(-6, "terrain curriculum buffers missing");
+    s->B = *b; s->bound = true;
+    return 0;
+}
+
+int lg_set_params(lg_sim *s, const lg_params *p) {
+    if (!s || !p) return fail(-1, "null argument");
+    if (p->num_envs != s->P.num_envs || p->control_type != s->P.control_type) return fail(-7, "num_envs / control_type cannot change after create");
+    s->P = *p;
+    return upload_tables(s);
+}
+
+int lg_step(lg_sim *s, const float *actions, int64_t common_step_counter, void *stream) {
+    if (!s || !s->bound) return fail(-8, "lg_bind has not been called");
+    if (!actions) return fail(-1, "null actions");
+    KArgs a; fill_args(s, a, common_step_counter); a.actions_in = actions;
+    hipStream_t st = (hipStream_t)stream;
+    const bool hf = s->P.terrain_type == LG_TERRAIN_HEIGHTFIELD;
+    const bool net = s->P.control_type == LG_CTRL_ACTUATOR_NET;
+    if (s->kind == ROBOT_ANYMAL) {
+        dim3 g(grid_for<AnymalTraits>(s->P.num_envs)), b(LG_BLOCK);
+        if (net && !hf) hipLaunchKernelGGL((k_step<AnymalTraits, true, false>), g, b, 0, st, a);
+        else if (net && hf) hipLaunchKernelGGL((k_step<AnymalTraits, true, true>), g, b, 0, st, a);
+        else if (!net && !hf) hipLaunchKernelGGL((k_step<AnymalTraits, false, false>), g, b, 0, st, a);
+        else hipLaunchKernelGGL((k_step<AnymalTraits, false, true>), g, b, 0, st, a);
+    } else {
+        dim3 g(grid_for<CassieTraits>(s->P.num_envs)), b(LG_BLOCK);
+        if (!hf) hipLaunchKernelGGL((k_step<CassieTraits, false, false>), g, b, 0, st, a);
+        else hipLaunchKernelGGL((k_step<CassieTraits, false, true>), g, b, 0, st, a);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int lg_reset_idx(lg_sim *s, const int32_t *env_ids, int32_t count, int64_t common_step_counter, void *stream) {
+    if (!s || !s->bound) return fail(-8, "lg_bind has not been called");
+    if (count <= 0) return 0;
+    if (!env_ids) return fail(-1, "null env_ids");
+    KArgs a; fill_args(s, a, common_step_counter); a.env_ids = env_ids; a.count = count;
+    hipStream_t st = (hipStream_t)stream;
+    const bool net = s->P.control_type == LG_CTRL_ACTUATOR_NET;
+    if (s->kind == ROBOT_ANYMAL) {
+        dim3 g(grid_for<AnymalTraits>(count)), b(LG_BLOCK);
+        if (net) hipLaunchKernelGGL((k_reset<AnymalTraits, true>), g, b, 0, st, a);
+        else hipLaunchKernelGGL((k_reset<AnymalTraits, false>), g, b, 0, st, a);
+    } else {
+        dim3 g(grid_for<CassieTraits>(count)), b(LG_BLOCK);
+        hipLaunchKernelGGL((k_reset<CassieTraits, false>), g, b, 0, st, a);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int lg_actuator_forward(lg_sim *s, const float *pos_err, const float *vel, float *torques, float *hidden, float *cell, int32_t rows, void *stream) {
+    if (!s || !s->has_net) return fail(-2, "no actuator weights");
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(k_actuator, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, s->d_weights, pos_err, vel, torques, hidden, cell, rows);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int lg_physics_substep(lg_sim *s, const float *torques, int32_t write_contacts, void *stream) {
+    if (!s || !s->bound) return fail(-8, "lg_bind has not been called");
+    KArgs a; fill_args(s, a, 0);
+    hipStream_t st = (hipStream_t)stream;
+    const bool hf = s->P.terrain_type == LG_TERRAIN_HEIGHTFIELD;
+    if (s->kind == ROBOT_ANYMAL) {
+        dim3 g(grid_for<AnymalTraits>(s->P.num_envs)), b(LG_BLOCK);
+        if (hf) hipLaunchKernelGGL((k_physics<AnymalTraits, true>), g, b, 0, st, a, torques, write_contacts);
+        else hipLaunchKernelGGL((k_physics<AnymalTraits, false>), g, b, 0, st, a, torques, write_contacts);
+    } else {
+        dim3 g(grid_for<CassieTraits>(s->P.num_envs)), b(LG_BLOCK);
+        if (hf) hipLaunchKernelGGL((k_physics<CassieTraits, true>), g, b, 0, st, a, torques, write_contacts);
+        else hipLaunchKernelGGL((k_physics<CassieTraits, false>), g, b, 0, st, a, torques, write_contacts);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int lg_compute_observations_only(lg_sim *s, int64_t common_step_counter, void *stream) {
+    if (!s || !s->bound) return fail(-8, "lg_bind has not been called");
+    KArgs a; fill_args(s, a, common_step_counter);
+    hipStream_t st = (hipStream_t)stream;
+    if (s->kind == ROBOT_ANYMAL) hipLaunchKernelGGL((k_obs<AnymalTraits>), dim3(grid_for<AnymalTraits>(s->P.num_envs)), dim3(LG_BLOCK), 0, st, a);
+    else hipLaunchKernelGGL((k_obs<CassieTraits>), dim3(grid_for<CassieTraits>(s->P.num_envs)), dim3(LG_BLOCK), 0, st, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

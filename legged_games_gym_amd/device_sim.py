@@ -1,0 +1,84 @@
+"""Torch-owned state buffers bound to one ``lg_sim`` handle.
+
+The reference lets Isaac Gym own ``root_states`` / ``dof_state`` /
+``contact_forces`` and wraps them zero-copy (``gymtorch.wrap_tensor``,
+``legged_robot.py:523-529``).  Here the direction is inverted: torch allocates
+every buffer (``packing.buffer_spec``) and the HIP library receives the raw
+device pointers through ``lg_bind``.  PyTorch is plumbing only: memory and
+the current HIP stream.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import capi
+from .utils import packing
+
+_TORCH_DTYPES = {"float32": torch.float32, "bool": torch.bool, "int64": torch.int64, "int32": torch.int32,
+                 "int16": torch.int16}
+
+
+class DeviceSim:
+    def __init__(self, params: capi.lg_params, model: capi.lg_robot_model, robot, device: torch.device,
+                 actuator_weights: Optional[np.ndarray] = None):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError(
+                f"the legged-robot hot path runs on an AMD GPU only (got device {device}); there is no CPU product path")
+        self.device = device
+        self.params, self.model, self.robot = params, model, robot
+        self.sim = capi.Sim(params, model, actuator_weights, device.index or 0)
+        self.buf: Dict[str, torch.Tensor] = {}
+        for name, (shape, dt) in packing.buffer_spec(params, robot).items():
+            self.buf[name] = torch.zeros(shape, dtype=_TORCH_DTYPES[dt], device=device)
+        self.buf["friction_coeffs"].fill_(1.0)
+        self.rebind()
+
+    def set_terrain(self, height_samples: np.ndarray, terrain_origins: np.ndarray):
+        self.buf["height_samples"] = torch.from_numpy(np.ascontiguousarray(height_samples, dtype=np.int16)).to(self.device)
+        self.buf["terrain_origins"] = torch.from_numpy(np.ascontiguousarray(terrain_origins, dtype=np.float32)).to(self.device)
+        self.rebind()
+
+    def rebind(self):
+        self.sim.bind({k: v.data_ptr() for k, v in self.buf.items()})
+
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def step(self, actions: torch.Tensor, counter: int):
+        if actions.dtype != torch.float32 or not actions.is_contiguous() or actions.device != self.device:
+            actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
+        n = self.robot.num_dof
+        if actions.shape != (self.params.num_envs, n):
+            raise ValueError(f"actions must be [{self.params.num_envs},{n}], got {tuple(actions.shape)}")
+        self._keep = actions
+        self.sim.step(actions.data_ptr(), counter, self._stream())
+
+    def reset_idx(self, env_ids: torch.Tensor, counter: int):
+        ids = env_ids.to(device=self.device, dtype=torch.int32).contiguous()
+        if ids.numel() == 0:
+            return
+        self._keep_ids = ids
+        self.sim.reset_idx(ids.data_ptr(), ids.numel(), counter, self._stream())
+
+    def physics_substep(self, torques: torch.Tensor, write_contacts: bool = True):
+        t = torques.to(device=self.device, dtype=torch.float32).contiguous()
+        self._keep = t
+        self.sim.physics_substep(t.data_ptr(), int(write_contacts), self._stream())
+
+    def actuator_forward(self, pos_err, vel, hidden, cell):
+        pe = pos_err.to(self.device, torch.float32).contiguous().view(-1)
+        ve = vel.to(self.device, torch.float32).contiguous().view(-1)
+        out = torch.empty_like(pe)
+        self.sim.actuator_forward(pe.data_ptr(), ve.data_ptr(), out.data_ptr(), hidden.data_ptr(), cell.data_ptr(),
+                                  pe.numel(), self._stream())
+        return out
+
+    def compute_observations_only(self, counter: int):
+        self.sim.compute_observations_only(counter, self._stream())
+
+    def close(self):
+        self.sim.close()

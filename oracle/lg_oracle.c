@@ -1,0 +1,818 @@
+/*
+ * lg_oracle.c -- CPU oracle for the legged-robot hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * build, load or call this file.  The product (legged_games_gym_amd/) never
+ * does: it fails loudly when the HIP extension is missing.
+ *
+ * Two halves:
+ *  (1) TORCH-SIDE HALF -- a scalar, one-env-at-a-time restatement of
+ *      reference legged_gym/envs/base/legged_robot.py:80-230, 329-444, 831-969,
+ *      envs/anymal_c/anymal.py:56-81, envs/cassie/cassie.py:43-46,
+ *      utils/math.py:38-48 and of the [EXTERNAL] isaacgym.torch_utils helpers
+ *      (quat_rotate_inverse, quat_apply, torch_rand_float) it calls.  Pinned by
+ *      tests/golden (actuator net probe from the reference's own .pt weights,
+ *      numpy transcriptions of the cited lines).
+ *  (2) PHYSICS HALF -- the reference delegates gym.simulate() to PhysX
+ *      (closed source, absent): PARITY UNPINNED against PhysX.  This file
+ *      *defines* the rigid-body step the HIP kernels must reproduce:
+ *      floating-base articulated-body algorithm in world-aligned coordinates
+ *      about the base origin, implicit (backward-Euler) spring-damper contacts
+ *      and joint limits folded into the articulated inertias, two-pass
+ *      stick / slide / separate classification, semi-implicit Euler.
+ *      See DESIGN.md "Physics step".
+ *
+ * Same C-ABI as include/legged_hip.h with prefix lgo_ and HOST pointers.
+ * Plain C99, fp32 arithmetic throughout (double only where the reference does).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/legged_hip.h"
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------ types */
+typedef struct { float x, y, z; } v3;
+typedef struct { float A[6], H[9], M[6]; } ai6;     /* [[A,H],[H^T,M]], A,M sym (xx,xy,xz,yy,yz,zz) */
+typedef struct { v3 w, v; } sv6;                   /* spatial motion (w, v) or force (n, f) */
+
+struct lgo_sim {
+    lg_params      P;
+    lg_robot_model R;
+    float          W[LG_ACTUATOR_FLOATS];
+    int            has_net;
+    lg_buffers     B;
+    int            threads;
+};
+typedef struct lgo_sim lgo_sim;
+
+static char g_err[256] = "";
+const char *lgo_last_error(void) { return g_err; }
+int lgo_abi_version(void) { return LG_ABI_VERSION; }
+int lgo_sizeof(int which) {
+    switch (which) { case 0: return (int)sizeof(lg_params); case 1: return (int)sizeof(lg_robot_model);
+                     case 2: return (int)sizeof(lg_buffers); case 3: return (int)sizeof(lg_point); default: return -1; }
+}
+
+/* ------------------------------------------------------------------ small vector algebra */
+static inline v3 V(float x, float y, float z) { v3 r = {x, y, z}; return r; }
+static inline v3 add(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline v3 sub(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline v3 scl(v3 a, float s) { return V(a.x * s, a.y * s, a.z * s); }
+static inline float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline v3 cross(v3 a, v3 b) { return V(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+static inline v3 mv(const float *R, v3 a) {     /* row-major 3x3 times vector */
+    return V(R[0] * a.x + R[1] * a.y + R[2] * a.z, R[3] * a.x + R[4] * a.y + R[5] * a.z, R[6] * a.x + R[7] * a.y + R[8] * a.z);
+}
+static inline v3 symv(const float *S, v3 a) {   /* symmetric (xx,xy,xz,yy,yz,zz) times vector */
+    return V(S[0] * a.x + S[1] * a.y + S[2] * a.z, S[1] * a.x + S[3] * a.y + S[4] * a.z, S[2] * a.x + S[4] * a.y + S[5] * a.z);
+}
+static inline void mm(const float *A, const float *B, float *C) {
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++)
+        C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+static void quat_to_mat(const float *q, float *R) {   /* q = xyzw, assumed unit */
+    float x = q[0], y = q[1], z = q[2], w = q[3];
+    R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * w);     R[2] = 2 * (x * z + y * w);
+    R[3] = 2 * (x * y + z * w);     R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * w);
+    R[6] = 2 * (x * z - y * w);     R[7] = 2 * (y * z + x * w);     R[8] = 1 - 2 * (x * x + y * y);
+}
+/* [EXTERNAL] isaacgym.torch_utils.quat_rotate_inverse, used at legged_robot.py:119-121 */
+static v3 quat_rotate_inverse(const float *q, v3 v) {
+    float qw = q[3]; v3 qv = V(q[0], q[1], q[2]);
+    v3 a = scl(v, 2.0f * qw * qw - 1.0f);
+    v3 b = scl(cross(qv, v), qw * 2.0f);
+    v3 c = scl(qv, dot(qv, v) * 2.0f);
+    return add(sub(a, b), c);
+}
+/* [EXTERNAL] isaacgym.torch_utils.quat_apply, used at legged_robot.py:338 and utils/math.py:42 */
+static v3 quat_apply(const float *q, v3 b) {
+    v3 xyz = V(q[0], q[1], q[2]);
+    v3 t = scl(cross(xyz, b), 2.0f);
+    return add(add(b, scl(t, q[3])), cross(xyz, t));
+}
+
+/* ------------------------------------------------------------------ Philox4x32-10 counter RNG */
+/* The reference draws from torch's global generator in call order; bit parity
+ * with that is neither possible nor needed.  Both the oracle and the HIP path
+ * use this counter-based stream keyed by (seed; env, step, purpose, block). */
+enum { RNG_NOISE = 0, RNG_CMD_STEP = 1, RNG_CMD_RESET = 2, RNG_DOF = 3, RNG_ROOT = 4, RNG_PUSH = 5,
+       RNG_TERRAIN = 6, RNG_NOISE_H = 7 };
+static inline void philox(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t out[4]) {
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+static inline float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }   /* [0,1), 24 bit like torch.rand */
+static inline void rand4(const lgo_sim *s, int env, int64_t step, int purpose, int block, float u[4]) {
+    uint32_t o[4];
+    philox(s->P.seed, (uint32_t)env, (uint32_t)step, (uint32_t)purpose, (uint32_t)block, o);
+    for (int i = 0; i < 4; i++) u[i] = u01(o[i]);
+}
+static inline float urange(float lo, float hi, float u) { return (hi - lo) * u + lo; }   /* torch_rand_float */
+
+/* ------------------------------------------------------------------ actuator network (anymal.py:71-78) */
+static inline float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+/* TorchScript LSTMsea.forward (anydrive_v3_lstm.pt: code/__torch__/models.py):
+ *   x*in_scale -> LSTM(2,8,num_layers=2), gate order i,f,g,o -> out_scale*Linear(8,1) */
+static float actuator_row(const float *W, float pos_err, float vel, float *h0, float *c0, float *h1, float *c1) {
+    const float *in_scale = W, *out_scale = W + 2;
+    const float *Wih0 = W + 3, *Whh0 = Wih0 + 64, *bih0 = Whh0 + 256, *bhh0 = bih0 + 32;
+    const float *Wih1 = bhh0 + 32, *Whh1 = Wih1 + 256, *bih1 = Whh1 + 256, *bhh1 = bih1 + 32;
+    const float *lw = bhh1 + 32, *lb = lw + 8;
+    float x0 = pos_err * in_scale[0], x1 = vel * in_scale[1];
+    float g[32], hn[8];
+    for (int r = 0; r < 32; r++) {
+        float a = Wih0[2 * r] * x0 + Wih0[2 * r + 1] * x1 + bih0[r];
+        float b = bhh0[r];
+        for (int k = 0; k < 8; k++) b += Whh0[8 * r + k] * h0[k];
+        g[r] = a + b;
+    }
+    for (int u = 0; u < 8; u++) {
+        float c = sigm(g[8 + u]) * c0[u] + sigm(g[u]) * tanhf(g[16 + u]);
+        c0[u] = c; hn[u] = sigm(g[24 + u]) * tanhf(c);
+    }
+    for (int u = 0; u < 8; u++) h0[u] = hn[u];
+    for (int r = 0; r < 32; r++) {
+        float a = bih1[r], b = bhh1[r];
+        for (int k = 0; k < 8; k++) { a += Wih1[8 * r + k] * h0[k]; b += Whh1[8 * r + k] * h1[k]; }
+        g[r] = a + b;
+    }
+    for (int u = 0; u < 8; u++) {
+        float c = sigm(g[8 + u]) * c1[u] + sigm(g[u]) * tanhf(g[16 + u]);
+        c1[u] = c; hn[u] = sigm(g[24 + u]) * tanhf(c);
+    }
+    float y = lb[0];
+    for (int u = 0; u < 8; u++) { h1[u] = hn[u]; y += lw[u] * hn[u]; }
+    return out_scale[0] * y;
+}
+
+int lgo_actuator_forward(lgo_sim *s, const float *pos_err, const float *vel, float *torques,
+                         float *hidden, float *cell, int32_t rows, void *stream) {
+    (void)stream;
+    if (!s->has_net) { snprintf(g_err, sizeof g_err, "no actuator weights"); return -2; }
+    for (int r = 0; r < rows; r++)
+        torques[r] = actuator_row(s->W, pos_err[r], vel[r], hidden + (size_t)r * 8, cell + (size_t)r * 8,
+                                  hidden + ((size_t)rows + r) * 8, cell + ((size_t)rows + r) * 8);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ articulated-inertia helpers */
+static void ai_zero(ai6 *I) { memset(I, 0, sizeof *I); }
+static void ai_add(ai6 *a, const ai6 *b) {
+    for (int i = 0; i < 6; i++) { a->A[i] += b->A[i]; a->M[i] += b->M[i]; }
+    for (int i = 0; i < 9; i++) a->H[i] += b->H[i];
+}
+/* point mass `m` at c:  A += m(|c|^2 1 - c c^T), H += m [c]x, M += m 1 */
+static void ai_add_point(ai6 *I, float m, v3 c) {
+    float cc = dot(c, c);
+    I->A[0] += m * (cc - c.x * c.x); I->A[1] -= m * c.x * c.y; I->A[2] -= m * c.x * c.z;
+    I->A[3] += m * (cc - c.y * c.y); I->A[4] -= m * c.y * c.z; I->A[5] += m * (cc - c.z * c.z);
+    I->H[1] -= m * c.z; I->H[2] += m * c.y; I->H[3] += m * c.z; I->H[5] -= m * c.x; I->H[6] -= m * c.y; I->H[7] += m * c.x;
+    I->M[0] += m; I->M[3] += m; I->M[5] += m;
+}
+/* I += k * g g^T with g = (gw, gv) */
+static void ai_add_rank1(ai6 *I, float k, v3 gw, v3 gv) {
+    float w[3] = {gw.x, gw.y, gw.z}, v[3] = {gv.x, gv.y, gv.z};
+    int t = 0;
+    for (int i = 0; i < 3; i++) for (int j = i; j < 3; j++, t++) { I->A[t] += k * w[i] * w[j]; I->M[t] += k * v[i] * v[j]; }
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) I->H[3 * i + j] += k * w[i] * v[j];
+}
+static sv6 ai_mul(const ai6 *I, sv6 s) {      /* [[A,H],[H^T,M]] (w;v) */
+    sv6 r;
+    r.w = add(symv(I->A, s.w), mv(I->H, s.v));
+    r.v = add(V(I->H[0] * s.w.x + I->H[3] * s.w.y + I->H[6] * s.w.z,
+                I->H[1] * s.w.x + I->H[4] * s.w.y + I->H[7] * s.w.z,
+                I->H[2] * s.w.x + I->H[5] * s.w.y + I->H[8] * s.w.z), symv(I->M, s.v));
+    return r;
+}
+static inline float sdot(sv6 a, sv6 b) { return dot(a.w, b.w) + dot(a.v, b.v); }
+static inline sv6 sadd(sv6 a, sv6 b) { sv6 r = {add(a.w, b.w), add(a.v, b.v)}; return r; }
+static inline sv6 sscl(sv6 a, float k) { sv6 r = {scl(a.w, k), scl(a.v, k)}; return r; }
+
+/* solve [[A,H],[H^T,M]] x = b for SPD 6x6 by LDL^T */
+static int solve6(const ai6 *I, const float *b, float *x) {
+    float m[6][6];
+    static const int ix[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+        m[i][j] = I->A[ix[i][j]]; m[i + 3][j + 3] = I->M[ix[i][j]];
+        m[i][j + 3] = I->H[3 * i + j]; m[j + 3][i] = I->H[3 * i + j];
+    }
+    float L[6][6], D[6];
+    for (int j = 0; j < 6; j++) {
+        float d = m[j][j];
+        for (int k = 0; k < j; k++) d -= L[j][k] * L[j][k] * D[k];
+        if (!(d > 0.0f)) return -1;
+        D[j] = d;
+        for (int i = j + 1; i < 6; i++) {
+            float v = m[i][j];
+            for (int k = 0; k < j; k++) v -= L[i][k] * L[j][k] * D[k];
+            L[i][j] = v / d;
+        }
+    }
+    float y[6];
+    for (int i = 0; i < 6; i++) { float v = b[i]; for (int k = 0; k < i; k++) v -= L[i][k] * y[k]; y[i] = v; }
+    for (int i = 0; i < 6; i++) y[i] /= D[i];
+    for (int i = 5; i >= 0; i--) { float v = y[i]; for (int k = i + 1; k < 6; k++) v -= L[k][i] * x[k]; x[i] = v; }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ terrain */
+static inline float hf_at(const lgo_sim *s, int ix, int iy) {
+    if (ix < 0) ix = 0; if (iy < 0) iy = 0;
+    if (ix > s->P.hf_rows - 1) ix = s->P.hf_rows - 1;
+    if (iy > s->P.hf_cols - 1) iy = s->P.hf_cols - 1;
+    return (float)s->B.height_samples[(size_t)ix * s->P.hf_cols + iy] * s->P.hf_vertical_scale;
+}
+/* Ground height and unit normal under world point (x,y).  Plane: z=0.
+ * Height field: bilinear patch of the 4 surrounding samples (the collision
+ * surface of the built-in engine; the reference hands the same int16 grid to
+ * PhysX, legged_robot.py:619-637). */
+static void ground_query(const lgo_sim *s, float x, float y, float *h, v3 *n) {
+    if (s->P.terrain_type == LG_TERRAIN_PLANE || !s->B.height_samples) { *h = 0.0f; *n = V(0, 0, 1); return; }
+    float inv = 1.0f / s->P.hf_horizontal_scale;
+    float gx = (x + s->P.hf_border) * inv, gy = (y + s->P.hf_border) * inv;
+    float fx = floorf(gx), fy = floorf(gy);
+    int ix = (int)fx, iy = (int)fy;
+    float tx = gx - fx, ty = gy - fy;
+    float h00 = hf_at(s, ix, iy), h10 = hf_at(s, ix + 1, iy), h01 = hf_at(s, ix, iy + 1), h11 = hf_at(s, ix + 1, iy + 1);
+    float hx0 = h00 + (h10 - h00) * tx, hx1 = h01 + (h11 - h01) * tx;
+    *h = hx0 + (hx1 - hx0) * ty;
+    float dhdx = ((h10 - h00) + ((h11 - h01) - (h10 - h00)) * ty) * inv;
+    float dhdy = (hx1 - hx0) * inv;
+    float l = 1.0f / sqrtf(dhdx * dhdx + dhdy * dhdy + 1.0f);
+    *n = V(-dhdx * l, -dhdy * l, l);
+}
+
+/* ------------------------------------------------------------------ physics sub-step (stands in for legged_robot.py:92-96) */
+#define NB (1 + LG_MAX_DOF)
+#define NPTS (LG_MAX_BASE_POINTS + LG_MAX_LIMBS * LG_MAX_LIMB_POINTS)
+#define LG_CONTACT_PASSES 2
+
+typedef struct {
+    int   body;        /* dynamic body: 0 base, 1+dof */
+    int   report;
+    v3    r, n, vc;    /* r: rel. base origin (world axes); n: ground normal; vc: point velocity */
+    float depth, kn, bt, mu;
+    int   on;
+    v3    f;           /* resulting force (world) */
+} contact_t;
+
+static void physics_substep_env(const lgo_sim *s, int e, const float *tau, int write_contacts) {
+    const lg_robot_model *M = &s->R;
+    const lg_params *P = &s->P;
+    const int K = M->num_limbs, L = M->chain_len, nd = K * L;
+    const float dt = P->sim_dt;
+    float *root = s->B.root_states + (size_t)e * 13;
+    float *dof = s->B.dof_state + (size_t)e * nd * 2;
+    const v3 grav = V(P->gravity[0], P->gravity[1], P->gravity[2]);
+
+    /* ---- kinematics: everything in world axes, positions relative to the base origin O */
+    float Rb[NB][9];
+    v3 rb[NB], wb[NB], vb[NB];            /* body origin, angular velocity, velocity of the body point at O */
+    sv6 S[NB], C[NB];                     /* joint motion subspace and velocity-product acceleration */
+    quat_to_mat(root + 3, Rb[0]);
+    rb[0] = V(0, 0, 0); wb[0] = V(root[10], root[11], root[12]); vb[0] = V(root[7], root[8], root[9]);
+    for (int k = 0; k < K; k++) for (int j = 0; j < L; j++) {
+        int d = k * L + j, b = 1 + d, par = (j == 0) ? 0 : b - 1;
+        float q = dof[2 * d], qd = dof[2 * d + 1];
+        rb[b] = add(rb[par], mv(Rb[par], V(M->joint_pos[d][0], M->joint_pos[d][1], M->joint_pos[d][2])));
+        float R0[9];
+        mm(Rb[par], M->joint_rot[d], R0);
+        v3 ax = mv(R0, V(M->joint_axis[d][0], M->joint_axis[d][1], M->joint_axis[d][2]));
+        float sn = sinf(q), cs = cosf(q);
+        for (int c = 0; c < 3; c++) {       /* Rodrigues on each column of R0 about the world axis */
+            v3 col = V(R0[c], R0[3 + c], R0[6 + c]);
+            v3 rot = add(add(scl(col, cs), scl(cross(ax, col), sn)), scl(ax, dot(ax, col) * (1.0f - cs)));
+            Rb[b][c] = rot.x; Rb[b][3 + c] = rot.y; Rb[b][6 + c] = rot.z;
+        }
+        S[b].w = ax; S[b].v = cross(rb[b], ax);
+        wb[b] = add(wb[par], scl(ax, qd));
+        vb[b] = add(vb[par], scl(S[b].v, qd));
+        C[b].w = scl(cross(wb[b], S[b].w), qd);
+        C[b].v = scl(add(cross(wb[b], S[b].v), cross(vb[b], S[b].w)), qd);
+    }
+
+    /* ---- rigid-body inertias about O and bias forces (gyroscopic - gravity) */
+    ai6 I0[NB];
+    sv6 p0[NB];
+    for (int b = 0; b <= nd; b++) {
+        float m; v3 com; float Il[6];
+        if (b == 0) {
+            float dm = s->B.base_mass_delta ? s->B.base_mass_delta[e] : 0.0f;
+            m = M->base_mass + dm;
+            float sc = m / M->base_mass;          /* recomputeInertia=True (legged_robot.py:729): scale with mass */
+            for (int i = 0; i < 6; i++) Il[i] = M->base_inertia[i] * sc;
+            com = V(M->base_com[0], M->base_com[1], M->base_com[2]);
+        } else {
+            m = M->body_mass[b - 1];
+            for (int i = 0; i < 6; i++) Il[i] = M->body_inertia[b - 1][i];
+            com = V(M->body_com[b - 1][0], M->body_com[b - 1][1], M->body_com[b - 1][2]);
+        }
+        v3 c = add(rb[b], mv(Rb[b], com));
+        /* Ic = R Il R^T */
+        float Ilf[9] = {Il[0], Il[1], Il[2], Il[1], Il[3], Il[4], Il[2], Il[4], Il[5]}, T[9], Rt[9], Ic[9];
+        mm(Rb[b], Ilf, T);
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Rt[3 * i + j] = Rb[b][3 * j + i];
+        mm(T, Rt, Ic);
+        ai_zero(&I0[b]);
+        I0[b].A[0] = Ic[0]; I0[b].A[1] = Ic[1]; I0[b].A[2] = Ic[2]; I0[b].A[3] = Ic[4]; I0[b].A[4] = Ic[5]; I0[b].A[5] = Ic[8];
+        ai_add_point(&I0[b], m, c);
+        v3 l = scl(add(vb[b], cross(wb[b], c)), m);
+        v3 n = add(mv(Ic, wb[b]), cross(c, l));
+        v3 fg = scl(grav, m);
+        p0[b].w = sub(add(cross(wb[b], n), cross(vb[b], l)), cross(c, fg));
+        p0[b].v = sub(cross(wb[b], l), fg);
+    }
+
+    /* ---- contact candidates */
+    contact_t ct[NPTS];
+    int nc = 0;
+    float mu_env = 0.5f * ((s->B.friction_coeffs ? s->B.friction_coeffs[e] : 1.0f) + P->ground_friction);
+    for (int g = -1; g < K; g++) {
+        int np = (g < 0) ? M->num_base_points : M->num_limb_points[g];
+        for (int i = 0; i < np; i++) {
+            const lg_point *pt = (g < 0) ? &M->base_points[i] : &M->limb_points[g][i];
+            int b = (g < 0) ? 0 : 1 + g * L + pt->joint;
+            contact_t *c = &ct[nc];
+            c->body = b; c->report = pt->report_body;
+            c->r = add(rb[b], mv(Rb[b], V(pt->pos[0], pt->pos[1], pt->pos[2])));
+            float h;
+            ground_query(s, root[0] + c->r.x, root[1] + c->r.y, &h, &c->n);
+            c->depth = pt->radius - (root[2] + c->r.z - h) * c->n.z;
+            c->on = c->depth > -P->contact_margin;
+            c->vc = add(vb[b], cross(wb[b], c->r));
+            c->kn = P->contact_stiffness * dt + P->contact_damping;
+            c->bt = P->friction_damping;
+            c->mu = mu_env;
+            c->f = V(0, 0, 0);
+            nc++;
+        }
+    }
+
+    /* ---- articulated-body passes with implicit contact impedances */
+    sv6 U[NB], acc[NB];
+    float Dinv[NB], uu[NB];
+    for (int pass = 0; pass < LG_CONTACT_PASSES; pass++) {
+        ai6 IA[NB]; sv6 pA[NB];
+        for (int b = 0; b <= nd; b++) { IA[b] = I0[b]; pA[b] = p0[b]; }
+        for (int i = 0; i < nc; i++) if (ct[i].on) {
+            contact_t *c = &ct[i];
+            float vn = dot(c->n, c->vc);
+            v3 vt = sub(c->vc, scl(c->n, vn));
+            v3 f = sub(scl(c->n, P->contact_stiffness * c->depth - c->kn * vn), scl(vt, c->bt));
+            ai_add_point(&IA[c->body], dt * c->bt, c->r);
+            ai_add_rank1(&IA[c->body], dt * (c->kn - c->bt), cross(c->r, c->n), c->n);
+            pA[c->body].w = sub(pA[c->body].w, cross(c->r, f));
+            pA[c->body].v = sub(pA[c->body].v, f);
+        }
+        for (int k = 0; k < K; k++) for (int j = L - 1; j >= 0; j--) {
+            int d = k * L + j, b = 1 + d, par = (j == 0) ? 0 : b - 1;
+            float q = dof[2 * d], qd = dof[2 * d + 1];
+            U[b] = ai_mul(&IA[b], S[b]);
+            float D = sdot(S[b], U[b]) + M->dof_armature[d] + dt * M->dof_damping[d];
+            float u = tau[d] - sdot(S[b], pA[b]) - M->dof_damping[d] * qd;
+            if (M->dof_lower[d] <= M->dof_upper[d]) {       /* implicit joint-limit spring-damper */
+                /* active when the explicit prediction leaves [lower, upper]:
+                 * tau_l = -k (q' - lim) - b qd'  with q' = q + dt qd', qd' = qd + dt qdd */
+                float qp = q + dt * qd;
+                int lo = qp < M->dof_lower[d], hi = qp > M->dof_upper[d];
+                if (lo || hi) {
+                    float viol = q - (lo ? M->dof_lower[d] : M->dof_upper[d]);
+                    float kl = P->limit_stiffness * dt + P->limit_damping;
+                    D += dt * kl;
+                    u += -P->limit_stiffness * viol - kl * qd;
+                }
+            }
+            Dinv[b] = 1.0f / D; uu[b] = u;
+            /* Ia = IA - U U^T / D ; pa = pA + Ia c + U u / D ; accumulate on the parent */
+            ai6 Ia = IA[b];
+            ai_add_rank1(&Ia, -Dinv[b], U[b].w, U[b].v);
+            sv6 pa = sadd(sadd(pA[b], ai_mul(&Ia, C[b])), sscl(U[b], u * Dinv[b]));
+            if (par != 0) { ai_add(&IA[par], &Ia); pA[par] = sadd(pA[par], pa); }
+            else {
+                /* base accumulation happens in a fixed pairwise order (mirrors the quad-lane butterfly of the HIP kernel) */
+                IA[b] = Ia; pA[b] = pa;     /* stash on the first body of the limb */
+            }
+        }
+        {   /* base: I0 + contacts (already in IA[0]) + sum over limbs, pairwise (0+1)+(2+3) */
+            ai6 acc_I[LG_MAX_LIMBS]; sv6 acc_p[LG_MAX_LIMBS];
+            for (int k = 0; k < K; k++) { acc_I[k] = IA[1 + k * L]; acc_p[k] = pA[1 + k * L]; }
+            for (int stride = 1; stride < K; stride *= 2)
+                for (int k = 0; k + stride < K; k += 2 * stride) { ai_add(&acc_I[k], &acc_I[k + stride]); acc_p[k] = sadd(acc_p[k], acc_p[k + stride]); }
+            ai_add(&IA[0], &acc_I[0]); pA[0] = sadd(pA[0], acc_p[0]);
+        }
+        float rhs[6] = {-pA[0].w.x, -pA[0].w.y, -pA[0].w.z, -pA[0].v.x, -pA[0].v.y, -pA[0].v.z}, a0[6];
+        if (solve6(&IA[0], rhs, a0) != 0) memset(a0, 0, sizeof a0);
+        acc[0].w = V(a0[0], a0[1], a0[2]); acc[0].v = V(a0[3], a0[4], a0[5]);
+        for (int k = 0; k < K; k++) for (int j = 0; j < L; j++) {
+            int b = 1 + k * L + j, par = (j == 0) ? 0 : b - 1;
+            sv6 ap = sadd(acc[par], C[b]);
+            float qdd = (uu[b] - sdot(U[b], ap)) * Dinv[b];
+            acc[b] = sadd(ap, sscl(S[b], qdd));
+            uu[b] = qdd;                 /* reuse: joint acceleration */
+        }
+        /* evaluate contacts at the end-of-step velocity and (re)classify */
+        for (int i = 0; i < nc; i++) if (ct[i].on) {
+            contact_t *c = &ct[i];
+            v3 vn_ = add(c->vc, scl(add(acc[c->body].v, cross(acc[c->body].w, c->r)), dt));
+            float vn = dot(c->n, vn_);
+            v3 vt = sub(vn_, scl(c->n, vn));
+            float fn = P->contact_stiffness * c->depth - c->kn * vn;
+            if (fn <= 0.0f) { c->on = 0; c->f = V(0, 0, 0); continue; }
+            float vtn = sqrtf(dot(vt, vt)), ft = c->bt * vtn;
+            if (ft > c->mu * fn) {       /* sliding: secant viscosity that yields |f_t| = mu f_n at this slip speed */
+                c->bt = c->mu * fn / fmaxf(vtn, 1e-9f);
+                ft = c->mu * fn;
+            }
+            v3 tdir = (vtn > 1e-12f) ? scl(vt, 1.0f / vtn) : V(0, 0, 0);
+            c->f = sub(scl(c->n, fn), scl(tdir, ft));
+        }
+    }
+
+    /* ---- semi-implicit Euler */
+    for (int d = 0; d < nd; d++) {
+        float qd = dof[2 * d + 1] + dt * uu[1 + d];
+        float lim = M->dof_vel_limit[d];
+        if (lim > 0.0f) qd = fminf(fmaxf(qd, -lim), lim);
+        dof[2 * d + 1] = qd;
+        dof[2 * d] += dt * qd;
+    }
+    v3 w0 = wb[0], v0 = vb[0];
+    v3 a_lin = add(acc[0].v, cross(w0, v0));          /* classical acceleration of the base origin */
+    v3 w1 = add(w0, scl(acc[0].w, dt)), v1 = add(v0, scl(a_lin, dt));
+    root[7] = v1.x; root[8] = v1.y; root[9] = v1.z; root[10] = w1.x; root[11] = w1.y; root[12] = w1.z;
+    root[0] += dt * v1.x; root[1] += dt * v1.y; root[2] += dt * v1.z;
+    {   /* q <- normalize(q + dt/2 * (w,0) (x) q) */
+        float x = root[3], y = root[4], z = root[5], w = root[6], hx = 0.5f * dt * w1.x, hy = 0.5f * dt * w1.y, hz = 0.5f * dt * w1.z;
+        float nx = x + (hx * w + hy * z - hz * y), ny = y + (hy * w + hz * x - hx * z), nz = z + (hz * w + hx * y - hy * x);
+        float nw = w - (hx * x + hy * y + hz * z);
+        float inv = 1.0f / sqrtf(nx * nx + ny * ny + nz * nz + nw * nw);
+        root[3] = nx * inv; root[4] = ny * inv; root[5] = nz * inv; root[6] = nw * inv;
+    }
+    if (write_contacts) {
+        float *cf = s->B.contact_forces + (size_t)e * M->num_bodies * 3;
+        for (int i = 0; i < M->num_bodies * 3; i++) cf[i] = 0.0f;
+        for (int i = 0; i < nc; i++) { cf[3 * ct[i].report] += ct[i].f.x; cf[3 * ct[i].report + 1] += ct[i].f.y; cf[3 * ct[i].report + 2] += ct[i].f.z; }
+    }
+}
+
+int lgo_physics_substep(lgo_sim *s, const float *torques, int32_t write_contacts, void *stream) {
+    (void)stream;
+    const int nd = s->R.num_limbs * s->R.chain_len;
+#pragma omp parallel for schedule(static) num_threads(s->threads)
+    for (int e = 0; e < s->P.num_envs; e++) physics_substep_env(s, e, torques + (size_t)e * nd, write_contacts);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ torques (legged_robot.py:371-395, anymal.py:71-81) */
+static void compute_torques_env(const lgo_sim *s, int e, float *tau) {
+    const lg_params *P = &s->P;
+    const int nd = s->R.num_limbs * s->R.chain_len, N = P->num_envs;
+    const float *act = s->B.actions + (size_t)e * nd;
+    const float *dof = s->B.dof_state + (size_t)e * nd * 2;
+    for (int d = 0; d < nd; d++) {
+        float a = act[d] * P->action_scale, q = dof[2 * d], qd = dof[2 * d + 1], t;
+        if (P->control_type == LG_CTRL_ACTUATOR_NET) {
+            size_t row = (size_t)e * nd + d, plane = (size_t)N * nd;
+            t = actuator_row(s->W, a + P->default_dof_pos[d] - q, qd,
+                             s->B.sea_hidden_state + row * 8, s->B.sea_cell_state + row * 8,
+                             s->B.sea_hidden_state + (plane + row) * 8, s->B.sea_cell_state + (plane + row) * 8);
+        } else {
+            if (P->control_type == LG_CTRL_P) t = P->p_gains[d] * (a + P->default_dof_pos[d] - q) - P->d_gains[d] * qd;
+            else if (P->control_type == LG_CTRL_V)
+                t = P->p_gains[d] * (a - qd) - P->d_gains[d] * (qd - s->B.last_dof_vel[(size_t)e * nd + d]) / P->sim_dt;
+            else t = a;
+            t = fminf(fmaxf(t, -P->torque_limits[d]), P->torque_limits[d]);
+        }
+        tau[d] = t;
+    }
+}
+
+/* ------------------------------------------------------------------ post-physics (legged_robot.py:106-230, 329-444, 831-969) */
+static void resample_commands(const lgo_sim *s, int e, int64_t step, int purpose) {   /* :347-369 */
+    const lg_params *P = &s->P;
+    float *cmd = s->B.commands + (size_t)e * 4, u[4];
+    rand4(s, e, step, purpose, 0, u);
+    cmd[0] = urange(P->cmd_lin_vel_x[0], P->cmd_lin_vel_x[1], u[0]);
+    cmd[1] = urange(P->cmd_lin_vel_y[0], P->cmd_lin_vel_y[1], u[1]);
+    if (P->heading_command) cmd[3] = urange(P->cmd_heading[0], P->cmd_heading[1], u[2]);
+    else cmd[2] = urange(P->cmd_ang_vel_yaw[0], P->cmd_ang_vel_yaw[1], u[2]);
+    float keep = (sqrtf(cmd[0] * cmd[0] + cmd[1] * cmd[1]) > 0.2f) ? 1.0f : 0.0f;
+    cmd[0] *= keep; cmd[1] *= keep;
+}
+static float wrap_to_pi(float a) {                 /* utils/math.py:45-48 (float32 tensor, python scalars) */
+    const float two_pi = 6.2831855f, pi = 3.14159274f;
+    a = fmodf(a, two_pi); if (a < 0.0f) a += two_pi;      /* torch remainder: sign of the divisor */
+    if (a > pi) a -= two_pi;
+    return a;
+}
+static void get_heights(const lgo_sim *s, int e, float *out) {   /* :831-869 */
+    const lg_params *P = &s->P;
+    const float *root = s->B.root_states + (size_t)e * 13;
+    if (P->terrain_type == LG_TERRAIN_PLANE || !s->B.height_samples) { for (int i = 0; i < P->num_height_points; i++) out[i] = 0.0f; return; }
+    float qy[4] = {0, 0, root[5], root[6]};
+    float nrm = sqrtf(qy[2] * qy[2] + qy[3] * qy[3]);
+    nrm = fmaxf(nrm, 1e-9f);                       /* torch_utils.normalize: x / norm.clamp(min=eps) */
+    qy[2] /= nrm; qy[3] /= nrm;
+    for (int i = 0; i < P->num_height_points; i++) {
+        v3 p = quat_apply(qy, V(P->height_points[i][0], P->height_points[i][1], 0.0f));
+        float px = p.x + root[0] + P->hf_border, py = p.y + root[1] + P->hf_border;
+        long ix = (long)(px / P->hf_horizontal_scale), iy = (long)(py / P->hf_horizontal_scale);   /* .long() truncates */
+        if (ix < 0) ix = 0; if (ix > P->hf_rows - 2) ix = P->hf_rows - 2;
+        if (iy < 0) iy = 0; if (iy > P->hf_cols - 2) iy = P->hf_cols - 2;
+        const int16_t *H = s->B.height_samples;
+        int16_t h1 = H[ix * P->hf_cols + iy], h2 = H[(ix + 1) * P->hf_cols + iy], h3 = H[ix * P->hf_cols + iy + 1];
+        int16_t h = h1 < h2 ? h1 : h2; h = h < h3 ? h : h3;
+        out[i] = (float)h * P->hf_vertical_scale;
+    }
+}
+
+static void reset_env(const lgo_sim *s, int e, int64_t step) {     /* reset_idx :147-191 + anymal.py:56-60 */
+    const lg_params *P = &s->P; const lg_robot_model *M = &s->R;
+    const int K = M->num_limbs, nd = K * M->chain_len, N = P->num_envs;
+    float *root = s->B.root_states + (size_t)e * 13, *dof = s->B.dof_state + (size_t)e * nd * 2;
+    float u[4];
+    if (P->terrain_curriculum && s->B.terrain_levels) {           /* _update_terrain_curriculum :446-469 */
+        float *org = s->B.env_origins + (size_t)e * 3, *cmd = s->B.commands + (size_t)e * 4;
+        float dx = root[0] - org[0], dy = root[1] - org[1], dist = sqrtf(dx * dx + dy * dy);
+        int up = dist > P->terrain_env_length / 2;
+        int down = (dist < sqrtf(cmd[0] * cmd[0] + cmd[1] * cmd[1]) * P->max_episode_length_s * 0.5f) && !up;
+        int lvl = s->B.terrain_levels[e] + up - down;
+        if (lvl >= P->terrain_num_rows) { rand4(s, e, step, RNG_TERRAIN, 0, u); lvl = (int)(u[0] * P->terrain_num_rows); if (lvl >= P->terrain_num_rows) lvl = P->terrain_num_rows - 1; }
+        else if (lvl < 0) lvl = 0;
+        s->B.terrain_levels[e] = lvl;
+        const float *to = s->B.terrain_origins + ((size_t)lvl * P->terrain_num_cols + s->B.terrain_types[e]) * 3;
+        org[0] = to[0]; org[1] = to[1]; org[2] = to[2];
+    }
+    for (int d = 0; d < nd; d++) {                                /* _reset_dofs :397-412 */
+        if ((d & 3) == 0) rand4(s, e, step, RNG_DOF, d >> 2, u);
+        dof[2 * d] = P->default_dof_pos[d] * urange(0.5f, 1.5f, u[d & 3]);
+        dof[2 * d + 1] = 0.0f;
+    }
+    const float *org = s->B.env_origins + (size_t)e * 3;          /* _reset_root_states :414-436 */
+    for (int i = 0; i < 13; i++) root[i] = P->base_init_state[i];
+    root[0] += org[0]; root[1] += org[1]; root[2] += org[2];
+    float v[4];
+    rand4(s, e, step, RNG_ROOT, 0, u); rand4(s, e, step, RNG_ROOT, 1, v);
+    if (P->custom_origins) { root[0] += urange(-1.0f, 1.0f, u[0]); root[1] += urange(-1.0f, 1.0f, u[1]); }
+    root[7] = urange(-0.5f, 0.5f, u[2]); root[8] = urange(-0.5f, 0.5f, u[3]);
+    root[9] = urange(-0.5f, 0.5f, v[0]); root[10] = urange(-0.5f, 0.5f, v[1]);
+    root[11] = urange(-0.5f, 0.5f, v[2]); root[12] = urange(-0.5f, 0.5f, v[3]);
+    resample_commands(s, e, step, RNG_CMD_RESET);
+    for (int d = 0; d < nd; d++) { s->B.last_actions[(size_t)e * nd + d] = 0.0f; s->B.last_dof_vel[(size_t)e * nd + d] = 0.0f; }
+    for (int k = 0; k < K; k++) s->B.feet_air_time[(size_t)e * K + k] = 0.0f;
+    s->B.episode_length_buf[e] = 0;
+    s->B.reset_buf[e] = 1;
+    for (int t = 0; t < P->num_reward_slots; t++) {
+        s->B.episode_sums_done[(size_t)t * N + e] = s->B.episode_sums[(size_t)t * N + e];
+        s->B.episode_sums[(size_t)t * N + e] = 0.0f;
+    }
+    if (s->B.sea_hidden_state) for (int l = 0; l < 2; l++) for (int d = 0; d < nd; d++) for (int k = 0; k < 8; k++) {
+        size_t i = (((size_t)l * N + e) * nd + d) * 8 + k;
+        s->B.sea_hidden_state[i] = 0.0f; s->B.sea_cell_state[i] = 0.0f;
+    }
+}
+
+static void compute_observations_env(const lgo_sim *s, int e, int64_t step) {   /* :212-230 + clip :100-101 */
+    const lg_params *P = &s->P;
+    const int nd = s->R.num_limbs * s->R.chain_len, K = s->R.num_limbs, Lc = s->R.chain_len;
+    const float *root = s->B.root_states + (size_t)e * 13, *dof = s->B.dof_state + (size_t)e * nd * 2;
+    float *obs = s->B.obs_buf + (size_t)e * P->num_obs;
+    const float *blv = s->B.base_lin_vel + (size_t)e * 3, *bav = s->B.base_ang_vel + (size_t)e * 3, *pg = s->B.projected_gravity + (size_t)e * 3;
+    const float *cmd = s->B.commands + (size_t)e * 4;
+    float nz[48];
+    for (int i = 0; i < 3; i++) {
+        obs[i] = blv[i] * P->obs_scale_lin_vel; nz[i] = P->noise_lin_vel;
+        obs[3 + i] = bav[i] * P->obs_scale_ang_vel; nz[3 + i] = P->noise_ang_vel;
+        obs[6 + i] = pg[i]; nz[6 + i] = P->noise_gravity;
+        nz[9 + i] = 0.0f;
+    }
+    obs[9] = cmd[0] * P->obs_scale_lin_vel; obs[10] = cmd[1] * P->obs_scale_lin_vel; obs[11] = cmd[2] * P->obs_scale_ang_vel;
+    for (int d = 0; d < nd; d++) {
+        obs[12 + d] = (dof[2 * d] - P->default_dof_pos[d]) * P->obs_scale_dof_pos; nz[12 + d] = P->noise_dof_pos;
+        obs[24 + d] = dof[2 * d + 1] * P->obs_scale_dof_vel; nz[24 + d] = P->noise_dof_vel;
+        obs[36 + d] = s->B.actions[(size_t)e * nd + d]; nz[36 + d] = 0.0f;
+    }
+    if (P->measure_heights) {
+        const float *mh = s->B.measured_heights + (size_t)e * P->num_height_points;
+        for (int i = 0; i < P->num_height_points; i++) {
+            float h = root[2] - 0.5f - mh[i];
+            obs[48 + i] = fminf(fmaxf(h, -1.0f), 1.0f) * P->obs_scale_height;
+        }
+    }
+    if (P->add_noise) {
+        /* element (group g of 4, limb k, j<L) of the first 48 draws from block (g*K+k)*2 + j/4, lane j%4 */
+        for (int g = 0; g < 4; g++) for (int k = 0; k < K; k++) for (int j = 0; j < Lc; j++) {
+            float u[4];
+            rand4(s, e, step, RNG_NOISE, (g * K + k) * 2 + (j >> 2), u);
+            int i = g * 12 + k * Lc + j;
+            obs[i] += (2.0f * u[j & 3] - 1.0f) * nz[i];
+        }
+        if (P->measure_heights) for (int i = 0; i < P->num_height_points; i++) {
+            float u[4];
+            rand4(s, e, step, RNG_NOISE_H, i >> 2, u);
+            obs[48 + i] += (2.0f * u[i & 3] - 1.0f) * P->noise_height;
+        }
+    }
+    for (int i = 0; i < P->num_obs; i++) obs[i] = fminf(fmaxf(obs[i], -P->clip_observations), P->clip_observations);
+}
+
+static void post_physics_env(const lgo_sim *s, int e, int64_t step) {
+    const lg_params *P = &s->P; const lg_robot_model *M = &s->R;
+    const int K = M->num_limbs, nd = K * M->chain_len, N = P->num_envs, nb = M->num_bodies;
+    float *root = s->B.root_states + (size_t)e * 13, *dof = s->B.dof_state + (size_t)e * nd * 2;
+    const float *cf = s->B.contact_forces + (size_t)e * nb * 3;
+    float *cmd = s->B.commands + (size_t)e * 4;
+    const float *act = s->B.actions + (size_t)e * nd, *tq = s->B.torques + (size_t)e * nd;
+    float *lact = s->B.last_actions + (size_t)e * nd, *ldv = s->B.last_dof_vel + (size_t)e * nd;
+
+    s->B.episode_length_buf[e] += 1;                                               /* :114 */
+    v3 blv = quat_rotate_inverse(root + 3, V(root[7], root[8], root[9]));          /* :118-121 */
+    v3 bav = quat_rotate_inverse(root + 3, V(root[10], root[11], root[12]));
+    v3 pg = quat_rotate_inverse(root + 3, V(0, 0, -1));
+    float *o;
+    o = s->B.base_lin_vel + (size_t)e * 3; o[0] = blv.x; o[1] = blv.y; o[2] = blv.z;
+    o = s->B.base_ang_vel + (size_t)e * 3; o[0] = bav.x; o[1] = bav.y; o[2] = bav.z;
+    o = s->B.projected_gravity + (size_t)e * 3; o[0] = pg.x; o[1] = pg.y; o[2] = pg.z;
+
+    /* _post_physics_step_callback :329-345 */
+    if (s->B.episode_length_buf[e] % P->resample_interval == 0) resample_commands(s, e, step, RNG_CMD_STEP);
+    if (P->heading_command) {
+        v3 fwd = quat_apply(root + 3, V(1, 0, 0));
+        float heading = atan2f(fwd.y, fwd.x);
+        cmd[2] = fminf(fmaxf(0.5f * wrap_to_pi(cmd[3] - heading), -1.0f), 1.0f);
+    }
+    if (P->measure_heights) get_heights(s, e, s->B.measured_heights + (size_t)e * P->num_height_points);
+    if (P->push_interval > 0 && step % P->push_interval == 0) {                    /* _push_robots :438-444 */
+        float u[4]; rand4(s, e, step, RNG_PUSH, 0, u);
+        root[7] = urange(-P->max_push_vel, P->max_push_vel, u[0]);
+        root[8] = urange(-P->max_push_vel, P->max_push_vel, u[1]);
+    }
+
+    /* check_termination :139-145 */
+    int contact_term = 0;
+    for (int b = 0; b < nb; b++) if (M->termination_mask >> b & 1u) {
+        float n = sqrtf(cf[3 * b] * cf[3 * b] + cf[3 * b + 1] * cf[3 * b + 1] + cf[3 * b + 2] * cf[3 * b + 2]);
+        if (n > 1.0f) contact_term = 1;
+    }
+    int time_out = s->B.episode_length_buf[e] > P->max_episode_length;
+    int reset = contact_term || time_out;
+    s->B.time_out_buf[e] = (uint8_t)time_out;
+    s->B.reset_buf[e] = (uint8_t)reset;
+
+    /* compute_reward :193-210, terms :872-969 + cassie.py:43-46 */
+    float term[LG_NUM_REWARD_TERMS];
+    const float *sc = P->reward_scale;
+    float cmd_xy = sqrtf(cmd[0] * cmd[0] + cmd[1] * cmd[1]);
+    float mh_mean = 0.0f;   /* base_height uses root z - measured heights (0 on the plane / when not measuring, :562) */
+    if (P->measure_heights) {
+        const float *mh = s->B.measured_heights + (size_t)e * P->num_height_points;
+        float acc = 0.0f; for (int i = 0; i < P->num_height_points; i++) acc += root[2] - mh[i];
+        mh_mean = acc / (float)P->num_height_points;
+    } else mh_mean = root[2];
+    float s_ar = 0, s_acc = 0, s_lim = 0, s_dv = 0, s_dvl = 0, s_tl = 0, s_tq = 0, s_ss = 0;
+    for (int d = 0; d < nd; d++) {
+        float q = dof[2 * d], qd = dof[2 * d + 1];
+        float da = lact[d] - act[d]; s_ar += da * da;
+        float dd = (ldv[d] - qd) / P->dt_policy; s_acc += dd * dd;
+        float ol = -fminf(q - P->soft_pos_lower[d], 0.0f); ol += fmaxf(q - P->soft_pos_upper[d], 0.0f); s_lim += ol;
+        s_dv += qd * qd;
+        s_dvl += fminf(fmaxf(fabsf(qd) - P->dof_vel_limits[d] * P->soft_dof_vel_limit, 0.0f), 1.0f);
+        s_tl += fmaxf(fabsf(tq[d]) - P->torque_limits[d] * P->soft_torque_limit, 0.0f);
+        s_tq += tq[d] * tq[d];
+        s_ss += fabsf(q - P->default_dof_pos[d]);
+    }
+    float coll = 0.0f;
+    for (int b = 0; b < nb; b++) if (M->penalised_mask >> b & 1u) {
+        float n = sqrtf(cf[3 * b] * cf[3 * b] + cf[3 * b + 1] * cf[3 * b + 1] + cf[3 * b + 2] * cf[3 * b + 2]);
+        coll += (n > 0.1f) ? 1.0f : 0.0f;
+    }
+    float air = 0.0f, fcf = 0.0f; int stumble = 0, nfly = 0;
+    for (int k = 0; k < K; k++) {
+        const float *f = cf + 3 * M->foot_body[k];
+        float fn = sqrtf(f[0] * f[0] + f[1] * f[1] + f[2] * f[2]);
+        fcf += fmaxf(fn - P->max_contact_force, 0.0f);
+        if (sqrtf(f[0] * f[0] + f[1] * f[1]) > 5.0f * fabsf(f[2])) stumble = 1;
+        nfly += f[2] > 0.1f;
+    }
+    if (sc[LG_REW_FEET_AIR_TIME] != 0.0f) {        /* stateful; only runs when the term is registered (:583-602) */
+        for (int k = 0; k < K; k++) {
+            const float *f = cf + 3 * M->foot_body[k];
+            float *at = s->B.feet_air_time + (size_t)e * K + k; uint8_t *lc = s->B.last_contacts + (size_t)e * K + k;
+            int contact = f[2] > 1.0f, filt = contact || *lc;
+            *lc = (uint8_t)contact;
+            int first = (*at > 0.0f) && filt;
+            *at += P->dt_policy;
+            air += (*at - 0.5f) * (first ? 1.0f : 0.0f);
+            *at *= filt ? 0.0f : 1.0f;
+        }
+        air *= (cmd_xy > 0.1f) ? 1.0f : 0.0f;
+    }
+    term[LG_REW_ACTION_RATE] = s_ar;
+    term[LG_REW_ANG_VEL_XY] = bav.x * bav.x + bav.y * bav.y;
+    term[LG_REW_BASE_HEIGHT] = (mh_mean - P->base_height_target) * (mh_mean - P->base_height_target);
+    term[LG_REW_COLLISION] = coll;
+    term[LG_REW_DOF_ACC] = s_acc;
+    term[LG_REW_DOF_POS_LIMITS] = s_lim;
+    term[LG_REW_DOF_VEL] = s_dv;
+    term[LG_REW_DOF_VEL_LIMITS] = s_dvl;
+    term[LG_REW_FEET_AIR_TIME] = air;
+    term[LG_REW_FEET_CONTACT_FORCES] = fcf;
+    term[LG_REW_LIN_VEL_Z] = blv.z * blv.z;
+    term[LG_REW_NO_FLY] = (nfly == 1) ? 1.0f : 0.0f;
+    term[LG_REW_ORIENTATION] = pg.x * pg.x + pg.y * pg.y;
+    term[LG_REW_STAND_STILL] = s_ss * ((cmd_xy < 0.1f) ? 1.0f : 0.0f);
+    term[LG_REW_STUMBLE] = stumble ? 1.0f : 0.0f;
+    term[LG_REW_TERMINATION] = (reset && !time_out) ? 1.0f : 0.0f;
+    term[LG_REW_TORQUE_LIMITS] = s_tl;
+    term[LG_REW_TORQUES] = s_tq;
+    {
+        float ex = cmd[0] - blv.x, ey = cmd[1] - blv.y, ew = cmd[2] - bav.z;
+        term[LG_REW_TRACKING_LIN_VEL] = expf(-(ex * ex + ey * ey) / P->tracking_sigma);
+        term[LG_REW_TRACKING_ANG_VEL] = expf(-(ew * ew) / P->tracking_sigma);
+    }
+    float rew = 0.0f;
+    for (int t = 0; t < LG_NUM_REWARD_TERMS; t++) {
+        if (t == LG_REW_TERMINATION || P->reward_slot[t] < 0) continue;
+        float r = term[t] * sc[t];
+        rew += r;
+        s->B.episode_sums[(size_t)P->reward_slot[t] * N + e] += r;
+    }
+    if (P->only_positive_rewards) rew = fmaxf(rew, 0.0f);
+    if (P->reward_slot[LG_REW_TERMINATION] >= 0) {
+        float r = term[LG_REW_TERMINATION] * sc[LG_REW_TERMINATION];
+        rew += r;
+        s->B.episode_sums[(size_t)P->reward_slot[LG_REW_TERMINATION] * N + e] += r;
+    }
+    s->B.rew_buf[e] = rew;
+
+    for (int t = 0; t < P->num_reward_slots; t++) s->B.episode_sums_done[(size_t)t * N + e] = 0.0f;
+    if (reset) reset_env(s, e, step);                                              /* :128-129 */
+    compute_observations_env(s, e, step);                                          /* :130 */
+    for (int d = 0; d < nd; d++) { lact[d] = act[d]; ldv[d] = dof[2 * d + 1]; }     /* :132-133 */
+    for (int i = 0; i < 6; i++) s->B.last_root_vel[(size_t)e * 6 + i] = root[7 + i]; /* :134 */
+}
+
+/* ------------------------------------------------------------------ C-ABI */
+int lgo_create(const lg_params *params, const lg_robot_model *model, const float *actuator_weights, int device_id, lgo_sim **out) {
+    (void)device_id;
+    if (!params || !model || !out) { snprintf(g_err, sizeof g_err, "null argument"); return -1; }
+    if (params->abi_version != LG_ABI_VERSION) { snprintf(g_err, sizeof g_err, "ABI version %d != %d", params->abi_version, LG_ABI_VERSION); return -3; }
+    if (model->num_limbs * model->chain_len != LG_MAX_DOF || model->num_limbs > LG_MAX_LIMBS || model->chain_len > LG_MAX_CHAIN) {
+        snprintf(g_err, sizeof g_err, "model must be K limbs x L joints with K*L == 12"); return -4;
+    }
+    lgo_sim *s = (lgo_sim *)calloc(1, sizeof *s);
+    s->P = *params; s->R = *model;
+    if (actuator_weights) { memcpy(s->W, actuator_weights, sizeof s->W); s->has_net = 1; }
+    if (params->control_type == LG_CTRL_ACTUATOR_NET && !s->has_net) { free(s); snprintf(g_err, sizeof g_err, "actuator net control without weights"); return -2; }
+    const char *t = getenv("LGO_THREADS");
+    s->threads = t ? atoi(t) : 1;
+    if (s->threads < 1) s->threads = 1;
+    *out = s;
+    return 0;
+}
+void lgo_destroy(lgo_sim *s) { free(s); }
+int lgo_bind(lgo_sim *s, const lg_buffers *b) { s->B = *b; return 0; }
+int lgo_set_params(lgo_sim *s, const lg_params *p) { s->P = *p; return 0; }
+int lgo_set_threads(lgo_sim *s, int n) { s->threads = n < 1 ? 1 : n; return 0; }
+
+int lgo_step(lgo_sim *s, const float *actions, int64_t step, void *stream) {
+    (void)stream;
+    const int nd = s->R.num_limbs * s->R.chain_len;
+#pragma omp parallel for schedule(static) num_threads(s->threads)
+    for (int e = 0; e < s->P.num_envs; e++) {
+        float *act = s->B.actions + (size_t)e * nd, *tq = s->B.torques + (size_t)e * nd;
+        for (int d = 0; d < nd; d++) act[d] = fminf(fmaxf(actions[(size_t)e * nd + d], -s->P.clip_actions), s->P.clip_actions);  /* :86-87 */
+        for (int it = 0; it < s->P.decimation; it++) {                                                                          /* :90-96 */
+            compute_torques_env(s, e, tq);
+            physics_substep_env(s, e, tq, it == s->P.decimation - 1);
+        }
+        post_physics_env(s, e, step);                                                                                           /* :97 */
+    }
+    return 0;
+}
+
+int lgo_reset_idx(lgo_sim *s, const int32_t *env_ids, int32_t count, int64_t step, void *stream) {
+    (void)stream;
+    for (int i = 0; i < count; i++) reset_env(s, env_ids[i], step);
+    return 0;
+}
+int lgo_compute_observations_only(lgo_sim *s, int64_t step, void *stream) {
+    (void)stream;
+    for (int e = 0; e < s->P.num_envs; e++) compute_observations_env(s, e, step);
+    return 0;
+}

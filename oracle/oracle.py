@@ -1,0 +1,105 @@
+"""Python handle on the CPU oracle (``oracle/lg_oracle.c``).  TEST INFRASTRUCTURE ONLY.
+
+May be imported by ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` leg -- never by ``legged_games_gym_amd``.  It reuses the
+package's ctypes struct definitions (the ABI is shared) and owns plain numpy
+buffers on the host.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Dict, Optional
+
+import numpy as np
+
+from legged_games_gym_amd import capi
+from legged_games_gym_amd.utils import packing
+
+HERE = os.path.dirname(os.path.realpath(__file__))
+LIB_PATH = os.path.join(HERE, "liblg_oracle.so")
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(HERE, "lg_oracle.c")
+    hdr = os.path.join(os.path.dirname(HERE), "include", "legged_hip.h")
+    stale = (not os.path.isfile(LIB_PATH)) or any(
+        os.path.isfile(f) and os.path.getmtime(f) > os.path.getmtime(LIB_PATH) for f in (src, hdr))
+    if force or stale:
+        subprocess.run(["make", "-C", HERE, "-s"], check=True)
+    return LIB_PATH
+
+
+def load():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = capi.bind_prototypes(C.CDLL(LIB_PATH), "lgo_")
+        _lib.lgo_set_threads.argtypes, _lib.lgo_set_threads.restype = [C.c_void_p, C.c_int], C.c_int
+    return _lib
+
+
+class OracleSim:
+    """Host-buffer twin of the HIP sim: same params/model structs, numpy arrays."""
+
+    def __init__(self, params: capi.lg_params, model: capi.lg_robot_model, robot,
+                 actuator_weights: Optional[np.ndarray] = None, threads: int = 1):
+        self.params, self.model, self.robot = params, model, robot
+        self.sim = capi.Sim(params, model, actuator_weights, 0, lib=load(), prefix="lgo_")
+        load().lgo_set_threads(self.sim.handle, int(threads))
+        self.buf: Dict[str, np.ndarray] = {}
+        for name, (shape, dt) in packing.buffer_spec(params, robot).items():
+            self.buf[name] = np.zeros(shape, dtype=np.dtype(dt) if dt != "bool" else np.uint8)
+        self.buf["friction_coeffs"][:] = 1.0
+        self.extra: Dict[str, np.ndarray] = {}
+        self.rebind()
+
+    def set_terrain(self, height_samples: np.ndarray, terrain_origins: np.ndarray):
+        self.extra["height_samples"] = np.ascontiguousarray(height_samples, dtype=np.int16)
+        self.extra["terrain_origins"] = np.ascontiguousarray(terrain_origins, dtype=np.float32)
+        self.rebind()
+
+    def rebind(self):
+        ptrs = {k: v.ctypes.data for k, v in self.buf.items()}
+        ptrs.update({k: v.ctypes.data for k, v in self.extra.items()})
+        self.sim.bind(ptrs)
+
+    def __getattr__(self, name):
+        buf = self.__dict__.get("buf", {})
+        if name in buf:
+            return buf[name]
+        raise AttributeError(name)
+
+    # views with the reference's names
+    @property
+    def dof_pos(self):
+        return self.buf["dof_state"].reshape(self.params.num_envs, -1, 2)[..., 0]
+
+    @property
+    def dof_vel(self):
+        return self.buf["dof_state"].reshape(self.params.num_envs, -1, 2)[..., 1]
+
+    def step(self, actions: np.ndarray, counter: int):
+        a = np.ascontiguousarray(actions, dtype=np.float32)
+        self.sim.step(a.ctypes.data, counter)
+
+    def reset_idx(self, env_ids, counter: int):
+        ids = np.ascontiguousarray(env_ids, dtype=np.int32)
+        self.sim.reset_idx(ids.ctypes.data, ids.size, counter)
+
+    def physics_substep(self, torques: np.ndarray, write_contacts: bool = True):
+        t = np.ascontiguousarray(torques, dtype=np.float32)
+        self.sim.physics_substep(t.ctypes.data, int(write_contacts))
+
+    def actuator_forward(self, pos_err, vel, hidden, cell):
+        pe = np.ascontiguousarray(pos_err, dtype=np.float32).ravel()
+        ve = np.ascontiguousarray(vel, dtype=np.float32).ravel()
+        out = np.zeros_like(pe)
+        assert hidden.dtype == np.float32 and cell.dtype == np.float32 and hidden.flags.c_contiguous
+        self.sim.actuator_forward(pe.ctypes.data, ve.ctypes.data, out.ctypes.data, hidden.ctypes.data, cell.ctypes.data, pe.size)
+        return out
+
+    def compute_observations_only(self, counter: int):
+        self.sim.compute_observations_only(counter)

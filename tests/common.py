@@ -1,0 +1,52 @@
+"""Shared helpers for the test-suite: build params/model for a task and make
+matching oracle (host) and HIP (device) sims."""
+import os
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.realpath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+from legged_games_gym_amd import capi  # noqa: E402
+from legged_games_gym_amd.envs import configs  # noqa: E402
+from legged_games_gym_amd.utils import packing  # noqa: E402
+from legged_games_gym_amd.utils.model_compiler import load_model  # noqa: E402
+
+TASK_CFG = {"anymal_c_flat": configs.AnymalCFlatCfg, "anymal_c_rough": configs.AnymalCRoughCfg,
+            "cassie": configs.CassieRoughCfg}
+
+
+def make_setup(task="anymal_c_flat", num_envs=64, seed=1, plane=None, terrain=None, tweak=None):
+    """Returns (cfg, robot, params, reward_names, model_struct, weights)."""
+    cfg = TASK_CFG[task]()
+    if plane or (plane is None and terrain is None and cfg.terrain.mesh_type != "plane"):
+        cfg.terrain.mesh_type = "plane"
+        cfg.terrain.curriculum = False
+    if tweak:
+        tweak(cfg)
+    robot = load_model(cfg.asset.file)
+    params, names = packing.build_params(cfg, robot, cfg.sim.dt, num_envs, seed, terrain=terrain)
+    model = capi.pack_model(robot, cfg.asset.foot_name, cfg.asset.penalize_contacts_on, cfg.asset.terminate_after_contacts_on)
+    weights = packing.load_actuator_weights() if params.control_type == capi.CTRL["actuator_net"] else None
+    return cfg, robot, params, names, model, weights
+
+
+def grid_origins(num_envs, spacing=3.0):
+    """Plane-case env origins (legged_robot.py:770-779)."""
+    cols = np.floor(np.sqrt(num_envs))
+    rows = np.ceil(num_envs / cols)
+    xx, yy = np.meshgrid(np.arange(rows), np.arange(cols), indexing="ij")
+    o = np.zeros((num_envs, 3), np.float32)
+    o[:, 0] = spacing * xx.flatten()[:num_envs]
+    o[:, 1] = spacing * yy.flatten()[:num_envs]
+    return o
+
+
+def randomize_env_params(num_envs, seed, friction_range=(0.0, 1.5), mass_range=(-5.0, 5.0)):
+    rng = np.random.default_rng(seed)
+    buckets = rng.uniform(friction_range[0], friction_range[1], 64).astype(np.float32)
+    fr = buckets[rng.integers(0, 64, num_envs)]
+    dm = rng.uniform(mass_range[0], mass_range[1], num_envs).astype(np.float32)
+    return fr, dm
