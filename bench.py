@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env-steps/s of the ANYmal-C flat rollout (BASELINE.json configs[1]).
+
+A "step" = one policy step of every env on this rank: random-init actor MLP
+[48,128,64,32,12] forward + Gaussian sampling (rsl_rl ActorCritic.act) followed by
+LeggedRobot.step (4 x [actuator net -> rigid-body step] + post-physics), inputs resident
+in HBM.  One process per GPU (RANK/LOCAL_RANK/WORLD_SIZE from the env); envs shard with no
+data-path collective, so scaling is weak; the only collectives are the timing barrier / max.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     -- the fused step kernel: algorithmic bytes (4022 B/env-step on
+                  flat ANYmal) x envs / mean kernel duration from HIP events recorded on the
+                  launch stream inside the timed region, against the 8 TB/s HBM peak.
+  cpu_baseline -- the CPU oracle (oracle/lg_oracle.c, OpenMP over envs, all host cores of
+                  this box) on a bounded sample of the same workload; rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.realpath(__file__))
+sys.path.insert(0, REPO)
+
+BYTES_PER_ENV_STEP = {"anymal_c_flat": 4022, "anymal_c_rough": 4762, "cassie": 1442}
+HBM_PEAK_GBS = 8000.0                                                                 # MI355X_MICROARCH.md
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--task", type=str, default="anymal_c_flat")
+    ap.add_argument("--num-envs", type=int, default=4096, help="envs per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+
+    import contextlib
+    import io
+    from legged_games_gym_amd.envs import task_registry  # registers tasks
+    from legged_games_gym_amd.utils import get_args
+    from legged_games_gym_amd.rl import ActorCritic
+    from legged_games_gym_amd.utils.helpers import class_to_dict
+
+    args = get_args(["--task", a.task, "--num_envs", str(a.num_envs), "--headless", "--sim_device", f"cuda:{local_rank}",
+                     "--rl_device", f"cuda:{local_rank}"])
+    env_cfg, train_cfg = task_registry.get_cfgs(a.task)
+    env_cfg.seed = train_cfg.seed + rank                  # rank-local RNG stream
+    with contextlib.redirect_stdout(io.StringIO()):
+        env, _ = task_registry.make_env(a.task, args, env_cfg=env_cfg)
+    env.set_fixed_commands(0.5, 0.0, 0.0)                 # "fixed command" of BASELINE.json
+    torch.manual_seed(train_cfg.seed)                     # random-init policy, same on every rank
+    pol = class_to_dict(train_cfg.policy)
+    policy = ActorCritic(env.num_obs, env.num_obs, env.num_actions, **pol).to(dev)
+    with contextlib.redirect_stdout(io.StringIO()):
+        obs, _ = env.reset()
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+
+    def one_step(obs, pair=None):
+        actions = policy.act(obs)
+        if pair is not None:
+            pair[0].record()
+        obs, _, _, _, _ = env.step(actions)               # the full VecEnv step (one lg_step call)
+        if pair is not None:
+            pair[1].record()
+        return obs
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.inference_mode():
+        for _ in range(a.warmup):
+            obs = one_step(obs)
+        sync()
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            obs = one_step(obs, ev[i])
+        sync()
+        elapsed = time.perf_counter() - t0
+    finite = bool(torch.isfinite(env.obs_buf).all()) and bool(torch.isfinite(env.root_states).all())
+    kern_ms = sum(s.elapsed_time(e) for s, e in ev) / max(a.steps, 1)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    out = None
+    if rank == 0:
+        total_envs = a.num_envs * world
+        value = total_envs * a.steps / elapsed
+        bpe = BYTES_PER_ENV_STEP.get(a.task, 4022)
+        achieved = bpe * a.num_envs / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": "env-steps/sec (whole node), ANYmal-C flat 4096 envs/GPU" if a.task == "anymal_c_flat" else f"env-steps/sec (whole node), {a.task}",
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{a.task}, {a.num_envs} envs/GPU, plane, actuator-net torques, random-init policy "
+                                   f"{[env.num_obs] + list(pol['actor_hidden_dims']) + [env.num_actions]} rollout (act = mu + sigma*eps), "
+                                   "fixed command (0.5,0,0), obs noise + friction/mass randomisation + pushes on",
+                       "envs_per_gpu": a.num_envs, "decimation": int(env.cfg.control.decimation), "sim_dt": float(env.sim_params.dt),
+                       "parallelism": f"env-sharded x{world}", "state_finite": finite},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "k_step<AnymalTraits,NET,plane>" if a.task != "cassie" else "k_step<CassieTraits>",
+                         "kernel_ms": kern_ms, "algorithmic_bytes_per_env_step": bpe,
+                         "note": "fused step is VALU/latency-bound at 4096 envs (256 waves on 1024 SIMDs); see DESIGN.md"},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(a):
+    """Time the CPU oracle on the same workload shape (own restatement: PhysX CPU is unavailable)."""
+    import numpy as np
+    from tests.common import make_setup, grid_origins, randomize_env_params
+    from oracle.oracle import OracleSim
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    N = a.num_envs
+    cfg, robot, p, names, model, w = make_setup(a.task, N)
+    o = OracleSim(p, model, robot, w, threads=cores)
+    o.buf["env_origins"][:] = grid_origins(N)
+    fr, dm = randomize_env_params(N, 1)
+    o.buf["friction_coeffs"][:] = fr
+    o.buf["base_mass_delta"][:] = dm
+    o.reset_idx(np.arange(N, dtype=np.int32), 0)
+    rng = np.random.default_rng(0)
+    acts = rng.standard_normal((8, N, 12)).astype(np.float32)
+    t0 = time.perf_counter()
+    o.step(acts[0], 1); o.step(acts[1], 2)
+    per = (time.perf_counter() - t0) / 2
+    steps = int(max(3, min(2000, a.cpu_seconds / max(per, 1e-6))))
+    t0 = time.perf_counter()
+    for i in range(steps):
+        o.step(acts[i % 8], 3 + i)
+    dt = time.perf_counter() - t0
+    return {"value": N * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{N} envs x {steps} policy steps of the same workload (env step only, N(0,1) actions), "
+                      f"oracle/lg_oracle.c with OpenMP over envs; PhysX CPU path of the reference is not runnable here"}
+
+
+if __name__ == "__main__":
+    main()

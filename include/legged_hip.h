@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LG_ABI_VERSION        3
+#define LG_ABI_VERSION        4
 
 #define LG_MAX_LIMBS          4
 #define LG_MAX_CHAIN          6
@@ -136,7 +136,10 @@ typedef struct lg_buffers {
     float   *measured_heights;  /* [N,num_height_points] or NULL */
     float   *sea_hidden_state, *sea_cell_state;                 /* [2,N*ndof,8] or NULL  T6 */
     float   *episode_sums;      /* [num_reward_slots,N]                                  T7 */
-    float   *episode_sums_done; /* [num_reward_slots,N] sums of envs reset this step (for extras) */
+    float   *episode_means;     /* [num_reward_slots+1] extras["episode"]: mean episode sum / max_episode_length_s over the
+                                   envs that reset in the latest step that had resets (legged_robot.py:179-183), stale
+                                   otherwise; last entry = mean terrain level (:186) */
+    float   *extras_accum;      /* [num_reward_slots+1] scratch: per-step sums + count, zeroed by the library */
     float   *env_origins;       /* [N,3] */
     int32_t *terrain_levels, *terrain_types;                    /* [N] or NULL           T9 */
     const float   *terrain_origins;   /* [rows,cols,3] or NULL */

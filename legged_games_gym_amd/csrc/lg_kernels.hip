@@ -685,9 +685,10 @@ __global__ void __launch_bounds__(LG_BLOCK) k_step(const KArgs A) {
             float *es = B.episode_sums + (size_t)slot * N + e;
             float sum = *es + r;
             *es = reset ? 0.0f : sum;
-            B.episode_sums_done[(size_t)slot * N + e] = reset ? sum : 0.0f;
+            if (reset) atomicAdd(B.extras_accum + slot, sum);          // extras["episode"] numerator (:179-183)
         }
     }
+    if (writer && reset) atomicAdd(B.extras_accum + P.num_reward_slots, 1.0f);
     if (P.only_positive_rewards) rew = fmaxf(rew, 0.0f);
     if (P.reward_slot[LG_REW_TERMINATION] >= 0) {
         const int slot = P.reward_slot[LG_REW_TERMINATION];
@@ -697,7 +698,7 @@ __global__ void __launch_bounds__(LG_BLOCK) k_step(const KArgs A) {
             float *es = B.episode_sums + (size_t)slot * N + e;
             float sum = *es + r;
             *es = reset ? 0.0f : sum;
-            B.episode_sums_done[(size_t)slot * N + e] = reset ? sum : 0.0f;
+            if (reset) atomicAdd(B.extras_accum + slot, sum);          // extras["episode"] numerator (:179-183)
         }
     }
 
@@ -817,9 +818,34 @@ __global__ void __launch_bounds__(LG_BLOCK) k_reset(const KArgs A) {
         B.episode_length_buf[e] = 0;
         B.reset_buf[e] = 1;
         for (int t = 0; t < P.num_reward_slots; t++) {
-            B.episode_sums_done[(size_t)t * N + e] = B.episode_sums[(size_t)t * N + e];
+            atomicAdd(B.extras_accum + t, B.episode_sums[(size_t)t * N + e]);
             B.episode_sums[(size_t)t * N + e] = 0.0f;
         }
+        atomicAdd(B.extras_accum + P.num_reward_slots, 1.0f);
+    }
+}
+
+// ------------------------------------------------------------------ extras["episode"] finisher (legged_robot.py:179-188)
+// One wave, launched right behind k_step / k_reset on the same stream: turns the accumulated sums + count into the
+// means the reference logs (kept stale when nothing reset, quirk Q4), re-zeroes the accumulator, and refreshes the
+// mean terrain level.  Keeps env.step() free of per-step torch kernels and host syncs.
+__global__ void __launch_bounds__(64) k_extras(const KArgs A) {
+    const lg_params &P = A.P;
+    const int R = P.num_reward_slots, t = threadIdx.x;
+    float cnt = A.B.extras_accum[R];
+    float v = (t < R) ? A.B.extras_accum[t] : 0.0f;
+    __syncthreads();
+    if (t < R) {
+        if (cnt > 0.0f) A.B.episode_means[t] = v / cnt / P.max_episode_length_s;
+        A.B.extras_accum[t] = 0.0f;
+    }
+    if (t == R) A.B.extras_accum[R] = 0.0f;
+    if (P.terrain_curriculum && A.B.terrain_levels) {
+        float acc = 0.0f;
+        for (int e = t; e < P.num_envs; e += 64) acc += (float)A.B.terrain_levels[e];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (t == 0) A.B.episode_means[R] = acc / (float)P.num_envs;
     }
 }
 
@@ -989,6 +1015,7 @@ int lg_sizeof(int which) {
 int lg_create(const lg_params *params, const lg_robot_model *model, const float *actuator_weights, int device_id, lg_sim **out) {
     if (!params || !model || !out) return fail(-1, "null argument");
     if (params->abi_version != LG_ABI_VERSION) return fail(-3, "ABI version mismatch");
+    static_assert(LG_NUM_REWARD_TERMS + 1 <= 64, "k_extras uses one wave");
     static_assert(sizeof(KArgs) <= 4096, "kernel arguments must fit the 4 KiB kernarg segment");
     RobotKind kind;
     if (check_topology<AnymalTraits>(model)) kind = ROBOT_ANYMAL;
@@ -1025,7 +1052,7 @@ int lg_bind(lg_sim *s, const lg_buffers *b) {
     const void *need[] = {b->root_states, b->dof_state, b->contact_forces, b->obs_buf, b->rew_buf, b->reset_buf, b->time_out_buf,
                           b->episode_length_buf, b->torques, b->actions, b->last_actions, b->last_dof_vel, b->last_root_vel, b->commands,
                           b->feet_air_time, b->last_contacts, b->base_lin_vel, b->base_ang_vel, b->projected_gravity, b->episode_sums,
-                          b->episode_sums_done, b->env_origins};
+                          b->episode_means, b->extras_accum, b->env_origins};
     for (size_t i = 0; i < sizeof need / sizeof *need; i++) if (!need[i]) return fail(-6, "a required buffer pointer is null");
     if (s->P.control_type == LG_CTRL_ACTUATOR_NET && (!b->sea_hidden_state || !b->sea_cell_state)) return fail(-6, "actuator state buffers missing");
     if (s->P.measure_heights && !b->measured_heights) return fail(-6, "measured_heights buffer missing");
@@ -1060,6 +1087,7 @@ int lg_step(lg_sim *s, const float *actions, int64_t common_step_counter, void *
         if (!hf) hipLaunchKernelGGL((k_step<CassieTraits, false, false>), g, b, 0, st, a);
         else hipLaunchKernelGGL((k_step<CassieTraits, false, true>), g, b, 0, st, a);
     }
+    hipLaunchKernelGGL(k_extras, dim3(1), dim3(64), 0, st, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1079,6 +1107,7 @@ int lg_reset_idx(lg_sim *s, const int32_t *env_ids, int32_t count, int64_t commo
         dim3 g(grid_for<CassieTraits>(count)), b(LG_BLOCK);
         hipLaunchKernelGGL((k_reset<CassieTraits, false>), g, b, 0, st, a);
     }
+    hipLaunchKernelGGL(k_extras, dim3(1), dim3(64), 0, st, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }

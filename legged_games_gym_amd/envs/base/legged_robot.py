@@ -1,0 +1,338 @@
+"""``LeggedRobot`` -- the VecEnv the reference exposes, on top of the fused HIP step.
+
+Surface mirror of reference ``legged_gym/envs/base/legged_robot.py``: same
+constructor signature, same attribute names / shapes / dtypes (SURVEY.md 8b
+"outer boundary"), same ``step`` / ``reset`` / ``reset_idx`` /
+``get_observations`` contract, so ``rsl_rl.OnPolicyRunner`` (or the bundled
+``legged_games_gym_amd.rl`` runner) drops in unchanged.
+
+What differs, by design: the reference runs ``step`` as a Python loop of ~150
+eager torch kernels around 4 PhysX calls (:80-137).  Here ``step`` is ONE call
+through the C-ABI (``lg_step``); every per-step quantity below is a view of a
+buffer the kernel wrote.  Python keeps only what is genuinely host-side:
+config parsing (:781-791), reward bookkeeping names (:583-607), creation-time
+domain randomisation (:261-327), env origins (:752-779) and the ``extras``
+dictionary (:179-191).
+
+Deliberate deviations from reference behaviour are listed in DESIGN.md
+("Quirks"): ``reset_buf``/``time_out_buf`` are persistent bool tensors (Q1,
+Q4), RNG is counter-based Philox rather than torch's global stream.
+"""
+import os
+
+import numpy as np
+import torch
+
+from legged_games_gym_amd import LEGGED_GYM_ROOT_DIR, capi
+from legged_games_gym_amd.device_sim import DeviceSim
+from legged_games_gym_amd.envs.base.base_task import BaseTask
+from legged_games_gym_amd.utils import packing
+from legged_games_gym_amd.utils.helpers import class_to_dict
+from legged_games_gym_amd.utils.model_compiler import load_model
+from legged_games_gym_amd.utils.terrain import Terrain
+
+
+class LeggedRobot(BaseTask):
+    def __init__(self, cfg, sim_params, physics_engine, sim_device, headless):
+        self.cfg = cfg
+        self.sim_params = sim_params
+        self.height_samples = None
+        self.debug_viz = False
+        self.init_done = False
+        self._parse_cfg(self.cfg)
+        super().__init__(self.cfg, sim_params, physics_engine, sim_device, headless)
+        self._init_buffers()
+        self._prepare_reward_function()
+        self.init_done = True
+
+    # ------------------------------------------------------------------ hot path
+    def step(self, actions):
+        """One policy step for all envs (reference :80-104), a single fused launch."""
+        self.common_step_counter += 1                     # :115 (the kernel needs the incremented value)
+        self._sim.step(actions, self.common_step_counter)
+        return self.obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf, self.extras
+
+    def post_physics_step(self):
+        raise RuntimeError("post_physics_step is fused into lg_step; call step()")
+
+    def reset_idx(self, env_ids):
+        """Reset the listed envs (reference :147-191) through ``lg_reset_idx``."""
+        if len(env_ids) == 0:
+            return
+        if self.cfg.commands.curriculum and (self.common_step_counter % self.max_episode_length == 0):
+            self.update_command_curriculum(env_ids)
+        if not self.init_done and self._params.terrain_curriculum:
+            # "don't change on initial reset" (:453-455)
+            self._params.terrain_curriculum = 0
+            self._sim.sim.set_params(self._params)
+            self._sim.reset_idx(env_ids, self.common_step_counter)
+            self._params.terrain_curriculum = 1
+            self._sim.sim.set_params(self._params)
+        else:
+            self._sim.reset_idx(env_ids, self.common_step_counter)
+        if self.cfg.commands.curriculum:
+            self.extras["episode"]["max_command_x"] = self.command_ranges["lin_vel_x"][1]
+
+    def _refresh_extras(self, force_ids=None):
+        """extras["episode"] / extras["time_outs"] (:179-191).  The means are computed by the library
+        (k_extras) into ``episode_means``; the dict holds 0-dim views, so no torch kernel and no host
+        sync happens here.  They stay stale on steps without resets (quirk Q4)."""
+        return
+
+    def _init_extras(self):
+        ep = self.extras.setdefault("episode", {})
+        for i, name in enumerate(self.reward_names_all):
+            ep["rew_" + name] = self._episode_means[i]
+        if self.cfg.terrain.curriculum:
+            ep["terrain_level"] = self._episode_means[len(self.reward_names_all)]
+        if self.cfg.commands.curriculum:
+            ep["max_command_x"] = self.command_ranges["lin_vel_x"][1]
+        if self.cfg.env.send_timeouts:
+            self.extras["time_outs"] = self.time_out_buf
+
+    def compute_observations(self):
+        """Recompute obs_buf from the current state (reference :212-230)."""
+        self._sim.compute_observations_only(self.common_step_counter)
+
+    # ------------------------------------------------------------------ creation
+    def create_sim(self):
+        """Terrain + robot model + device buffers (reference :232-251, :657-750)."""
+        self.up_axis_idx = 2
+        mesh_type = self.cfg.terrain.mesh_type
+        if mesh_type not in (None, "none", "plane", "heightfield", "trimesh"):
+            raise ValueError("Terrain mesh type not recognised. Allowed types are [None, plane, heightfield, trimesh]")
+        self.terrain = None
+        if mesh_type in ("heightfield", "trimesh"):
+            # 'trimesh' collides against the same height samples: the built-in engine has one
+            # terrain representation, the int16 height field the reference also feeds to _get_heights.
+            self.terrain = Terrain(self.cfg.terrain, self.num_envs)
+        self._create_envs()
+
+    def _create_envs(self):
+        cfg = self.cfg
+        asset_path = cfg.asset.file.format(LEGGED_GYM_ROOT_DIR=LEGGED_GYM_ROOT_DIR)
+        self.robot_model = load_model(asset_path, collapse_fixed_joints=cfg.asset.collapse_fixed_joints,
+                                      replace_cylinder_with_capsule=cfg.asset.replace_cylinder_with_capsule) \
+            if os.path.isfile(asset_path) else load_model(asset_path)
+        rm = self.robot_model
+        self.num_dof = self.num_dofs = rm.num_dof
+        self.num_bodies = rm.num_bodies
+        self.dof_names = list(rm.dof_names)
+        body_names = list(rm.body_names)
+        if self.num_actions != self.num_dof:
+            raise ValueError("num_actions must equal the number of DOFs")
+
+        seed = getattr(cfg, "seed", 1)
+        sim_dt = self.sim_params.dt
+        gravity = getattr(self.sim_params, "gravity", [0.0, 0.0, -9.81])
+        physx = getattr(self.sim_params, "physx", None)
+        contact_offset = getattr(physx, "contact_offset", 0.01) if physx is not None else 0.01
+        self._params, self.reward_names_all = packing.build_params(
+            cfg, rm, sim_dt, self.num_envs, seed if seed is not None and seed >= 0 else 1, gravity=gravity,
+            terrain=self.terrain, contact_offset=contact_offset)
+        self._model = capi.pack_model(rm, cfg.asset.foot_name, cfg.asset.penalize_contacts_on,
+                                      cfg.asset.terminate_after_contacts_on, armature=cfg.asset.armature)
+        weights = None
+        if self._params.control_type == capi.CTRL["actuator_net"]:
+            weights = packing.load_actuator_weights(
+                cfg.control.actuator_net_file.format(LEGGED_GYM_ROOT_DIR=LEGGED_GYM_ROOT_DIR))
+        self._sim = DeviceSim(self._params, self._model, rm, torch.device(self.device), weights)
+        b = self._sim.buf
+
+        # body index lookups by substring (:696-702, :733-750)
+        def idx(names):
+            out = []
+            for n in names:
+                out.extend(rm.bodies_matching(n))
+            return torch.tensor(out, dtype=torch.long, device=self.device)
+        self.feet_indices = torch.tensor(rm.bodies_matching(cfg.asset.foot_name), dtype=torch.long, device=self.device)
+        self.penalised_contact_indices = idx(cfg.asset.penalize_contacts_on)
+        self.termination_contact_indices = idx(cfg.asset.terminate_after_contacts_on)
+        self.body_names = body_names
+
+        # DOF limits (:299-314)
+        lo = torch.tensor(rm.dof_lower, dtype=torch.float, device=self.device)
+        hi = torch.tensor(rm.dof_upper, dtype=torch.float, device=self.device)
+        m, r = (lo + hi) / 2, hi - lo
+        self.dof_pos_limits = torch.stack((m - 0.5 * r * cfg.rewards.soft_dof_pos_limit,
+                                           m + 0.5 * r * cfg.rewards.soft_dof_pos_limit), dim=1)
+        self.dof_vel_limits = torch.tensor(rm.dof_velocity, dtype=torch.float, device=self.device)
+        self.torque_limits = torch.tensor(rm.dof_effort, dtype=torch.float, device=self.device)
+
+        init = cfg.init_state
+        self.base_init_state = torch.tensor(list(init.pos) + list(init.rot) + list(init.lin_vel) + list(init.ang_vel),
+                                            dtype=torch.float, device=self.device)
+        self._get_env_origins()
+
+        # creation-time domain randomisation (:261-285, :316-327): 64 friction buckets, per-env base mass
+        if cfg.domain_rand.randomize_friction:
+            fr = cfg.domain_rand.friction_range
+            bucket_ids = torch.randint(0, 64, (self.num_envs, 1))
+            buckets = (fr[1] - fr[0]) * torch.rand(64, 1) + fr[0]
+            self.friction_coeffs = buckets[bucket_ids]                       # [N,1,1] on the host, as in the reference
+            b["friction_coeffs"].copy_(self.friction_coeffs.view(-1).to(self.device))
+        if cfg.domain_rand.randomize_base_mass:
+            rng = cfg.domain_rand.added_mass_range
+            dm = np.array([np.random.uniform(rng[0], rng[1]) for _ in range(self.num_envs)], dtype=np.float32)
+            b["base_mass_delta"].copy_(torch.from_numpy(dm).to(self.device))
+        if self.terrain is not None:
+            self._sim.set_terrain(self.terrain.heightsamples, self.terrain.env_origins)
+            self.height_samples = self._sim.buf["height_samples"].view(self.terrain.tot_rows, self.terrain.tot_cols)
+            b["terrain_levels"].copy_(self.terrain_levels.to(torch.int32))
+            b["terrain_types"].copy_(self.terrain_types.to(torch.int32))
+            self.terrain_levels = b["terrain_levels"]
+            self.terrain_types = b["terrain_types"]
+
+        # initial actor poses (:714-719): origin + U(-1,1) xy (also on the plane, Q8); DOFs at the default pose
+        root = b["root_states"]
+        root[:] = self.base_init_state
+        root[:, :3] += self.env_origins
+        root[:, :2] += 2.0 * torch.rand(self.num_envs, 2, device=self.device) - 1.0
+        q0 = torch.tensor([init.default_joint_angles[n] for n in self.dof_names], dtype=torch.float, device=self.device)
+        b["dof_state"].view(self.num_envs, self.num_dof, 2)[..., 0] = q0
+
+    def _get_env_origins(self):
+        """Reference :752-779."""
+        cfg = self.cfg
+        origins = self._sim.buf["env_origins"]
+        if cfg.terrain.mesh_type in ("heightfield", "trimesh"):
+            self.custom_origins = True
+            max_init_level = cfg.terrain.max_init_terrain_level
+            if not cfg.terrain.curriculum:
+                max_init_level = cfg.terrain.num_rows - 1
+            self.terrain_levels = torch.randint(0, max_init_level + 1, (self.num_envs,), device=self.device)
+            self.terrain_types = torch.div(torch.arange(self.num_envs, device=self.device),
+                                           (self.num_envs / cfg.terrain.num_cols), rounding_mode="floor").to(torch.long)
+            self.max_terrain_level = cfg.terrain.num_rows
+            self.terrain_origins = torch.from_numpy(self.terrain.env_origins).to(self.device).to(torch.float)
+            origins[:] = self.terrain_origins[self.terrain_levels, self.terrain_types]
+        else:
+            self.custom_origins = False
+            num_cols = np.floor(np.sqrt(self.num_envs))
+            num_rows = np.ceil(self.num_envs / num_cols)
+            xx, yy = torch.meshgrid(torch.arange(num_rows), torch.arange(num_cols), indexing="ij")
+            spacing = cfg.env.env_spacing
+            origins[:, 0] = spacing * xx.flatten()[:self.num_envs].to(self.device)
+            origins[:, 1] = spacing * yy.flatten()[:self.num_envs].to(self.device)
+            origins[:, 2] = 0.0
+        self.env_origins = origins
+
+    # ------------------------------------------------------------------ buffers
+    def _init_buffers(self):
+        """Expose the kernel's buffers under the reference's names (:511-581)."""
+        b = self._sim.buf
+        N, n = self.num_envs, self.num_dof
+        self.root_states = b["root_states"]
+        self.dof_state = b["dof_state"]
+        self.dof_pos = self.dof_state.view(N, n, 2)[..., 0]
+        self.dof_vel = self.dof_state.view(N, n, 2)[..., 1]
+        self.base_quat = self.root_states[:, 3:7]
+        self.contact_forces = b["contact_forces"]
+        self.obs_buf, self.rew_buf = b["obs_buf"], b["rew_buf"]
+        self.reset_buf, self.time_out_buf = b["reset_buf"], b["time_out_buf"]
+        self.reset_buf.fill_(True)                                   # base_task.py:73 starts at ones
+        self.episode_length_buf = b["episode_length_buf"]
+        self.common_step_counter = 0
+        self.extras = {}
+        self.noise_scale_vec = self._get_noise_scale_vec(self.cfg)
+        self.gravity_vec = torch.tensor([0.0, 0.0, -1.0], device=self.device).repeat((N, 1))
+        self.forward_vec = torch.tensor([1.0, 0.0, 0.0], device=self.device).repeat((N, 1))
+        self.torques, self.actions = b["torques"], b["actions"]
+        self.last_actions, self.last_dof_vel, self.last_root_vel = b["last_actions"], b["last_dof_vel"], b["last_root_vel"]
+        self.commands = b["commands"]
+        s = self.obs_scales
+        self.commands_scale = torch.tensor([s.lin_vel, s.lin_vel, s.ang_vel], device=self.device, requires_grad=False)
+        self.feet_air_time, self.last_contacts = b["feet_air_time"], b["last_contacts"]
+        self.base_lin_vel, self.base_ang_vel, self.projected_gravity = b["base_lin_vel"], b["base_ang_vel"], b["projected_gravity"]
+        self.projected_gravity[:] = self.gravity_vec
+        if self.cfg.terrain.measure_heights:
+            self.height_points = self._init_height_points()
+            self.measured_heights = b["measured_heights"]
+        else:
+            self.measured_heights = 0
+        p = self._params
+        self.p_gains = torch.tensor(list(p.p_gains)[:n], dtype=torch.float, device=self.device)
+        self.d_gains = torch.tensor(list(p.d_gains)[:n], dtype=torch.float, device=self.device)
+        self.default_dof_pos = torch.tensor(list(p.default_dof_pos)[:n], dtype=torch.float, device=self.device).unsqueeze(0)
+        for i, name in enumerate(self.dof_names):
+            if not any(k in name for k in self.cfg.control.stiffness.keys()) and self.cfg.control.control_type in ["P", "V"]:
+                print(f"PD gain of joint {name} were not defined, setting them to zero")
+
+    def _prepare_reward_function(self):
+        """Reference :583-607: zero scales dropped, the rest multiplied by dt; episode sums per name."""
+        for key in list(self.reward_scales.keys()):
+            if self.reward_scales[key] == 0:
+                self.reward_scales.pop(key)
+            else:
+                self.reward_scales[key] *= self.dt
+        self.reward_names = [n for n in self.reward_scales.keys() if n != "termination"]
+        assert list(self.reward_scales.keys()) == self.reward_names_all
+        sums = self._sim.buf["episode_sums"]
+        self.episode_sums = {name: sums[i] for i, name in enumerate(self.reward_names_all)}
+        self._episode_means = self._sim.buf["episode_means"]
+        self._init_extras()
+
+    def _parse_cfg(self, cfg):
+        """Reference :781-791."""
+        self.dt = self.cfg.control.decimation * self.sim_params.dt
+        self.obs_scales = self.cfg.normalization.obs_scales
+        self.reward_scales = class_to_dict(self.cfg.rewards.scales)
+        self.command_ranges = class_to_dict(self.cfg.commands.ranges)
+        if self.cfg.terrain.mesh_type not in ["heightfield", "trimesh"]:
+            self.cfg.terrain.curriculum = False
+        self.max_episode_length_s = self.cfg.env.episode_length_s
+        self.max_episode_length = np.ceil(self.max_episode_length_s / self.dt)
+        self.cfg.domain_rand.push_interval = np.ceil(self.cfg.domain_rand.push_interval_s / self.dt)
+
+    def _get_noise_scale_vec(self, cfg):
+        """Reference :485-508 (the kernel applies the same per-segment scales)."""
+        noise_vec = torch.zeros(self.num_obs, device=self.device)
+        self.add_noise = self.cfg.noise.add_noise
+        ns, lvl, s = self.cfg.noise.noise_scales, self.cfg.noise.noise_level, self.obs_scales
+        noise_vec[:3] = ns.lin_vel * lvl * s.lin_vel
+        noise_vec[3:6] = ns.ang_vel * lvl * s.ang_vel
+        noise_vec[6:9] = ns.gravity * lvl
+        noise_vec[9:12] = 0.0
+        noise_vec[12:24] = ns.dof_pos * lvl * s.dof_pos
+        noise_vec[24:36] = ns.dof_vel * lvl * s.dof_vel
+        noise_vec[36:48] = 0.0
+        if self.cfg.terrain.measure_heights:
+            noise_vec[48:] = ns.height_measurements * lvl * s.height_measurements
+        return noise_vec
+
+    def _init_height_points(self):
+        """Reference :815-829."""
+        y = torch.tensor(self.cfg.terrain.measured_points_y, device=self.device, requires_grad=False)
+        x = torch.tensor(self.cfg.terrain.measured_points_x, device=self.device, requires_grad=False)
+        grid_x, grid_y = torch.meshgrid(x, y, indexing="ij")
+        self.num_height_points = grid_x.numel()
+        points = torch.zeros(self.num_envs, self.num_height_points, 3, device=self.device, requires_grad=False)
+        points[:, :, 0] = grid_x.flatten()
+        points[:, :, 1] = grid_y.flatten()
+        return points
+
+    # ------------------------------------------------------------------ curricula (host side)
+    def update_command_curriculum(self, env_ids):
+        """Reference :471-483; pushes the widened range to the device."""
+        if torch.mean(self.episode_sums["tracking_lin_vel"][env_ids]) / self.max_episode_length > 0.8 * \
+                self.reward_scales["tracking_lin_vel"]:
+            r = self.command_ranges["lin_vel_x"]
+            r[0] = np.clip(r[0] - 0.5, -self.cfg.commands.max_curriculum, 0.0)
+            r[1] = np.clip(r[1] + 0.5, 0.0, self.cfg.commands.max_curriculum)
+            self.set_command_ranges()
+
+    def set_command_ranges(self):
+        """Re-upload ``self.command_ranges`` (tooling such as play.py edits them)."""
+        capi._fill(self._params.cmd_lin_vel_x, self.command_ranges["lin_vel_x"])
+        capi._fill(self._params.cmd_lin_vel_y, self.command_ranges["lin_vel_y"])
+        capi._fill(self._params.cmd_ang_vel_yaw, self.command_ranges["ang_vel_yaw"])
+        capi._fill(self._params.cmd_heading, self.command_ranges["heading"])
+        self._sim.sim.set_params(self._params)
+
+    def set_fixed_commands(self, vx, vy, yaw):
+        """Benchmark helper (BASELINE.json: "fixed command"): pin the command and disable resampling."""
+        self.command_ranges["lin_vel_x"] = [vx, vx]
+        self.command_ranges["lin_vel_y"] = [vy, vy]
+        self.command_ranges["ang_vel_yaw"] = [yaw, yaw]
+        self.set_command_ranges()
+        self.commands[:, 0], self.commands[:, 1], self.commands[:, 2] = vx, vy, yaw

@@ -1,0 +1,97 @@
+"""``OnPolicyRunner`` with the constructor / learn / save / load / get_inference_policy surface the
+reference uses (``task_registry.py:154-161``, ``scripts/train.py:43``, ``scripts/play.py:59``);
+checkpoints are ``model_<it>.pt`` in ``log_dir`` so ``get_load_path`` (helpers.py:103-125) finds them."""
+import os
+import statistics
+import time
+from collections import deque
+
+import torch
+
+from .actor_critic import ActorCritic
+from .ppo import PPO
+
+
+class OnPolicyRunner:
+    def __init__(self, env, train_cfg, log_dir=None, device="cpu"):
+        self.cfg, self.alg_cfg, self.policy_cfg = train_cfg["runner"], train_cfg["algorithm"], train_cfg["policy"]
+        self.device, self.env = device, env
+        num_critic_obs = env.num_privileged_obs if env.num_privileged_obs is not None else env.num_obs
+        if self.cfg.get("policy_class_name", "ActorCritic") != "ActorCritic":
+            raise NotImplementedError("only the feed-forward ActorCritic is bundled")
+        actor_critic = ActorCritic(env.num_obs, num_critic_obs, env.num_actions, **self.policy_cfg).to(device)
+        self.alg = PPO(actor_critic, device=device, **self.alg_cfg)
+        self.num_steps_per_env = self.cfg["num_steps_per_env"]
+        self.save_interval = self.cfg["save_interval"]
+        self.alg.init_storage(env.num_envs, self.num_steps_per_env, [env.num_obs], [env.num_privileged_obs], [env.num_actions])
+        self.log_dir, self.writer = log_dir, None
+        self.tot_timesteps, self.tot_time, self.current_learning_iteration = 0, 0.0, 0
+        _, _ = self.env.reset()
+
+    def learn(self, num_learning_iterations, init_at_random_ep_len=False):
+        if init_at_random_ep_len:
+            self.env.episode_length_buf[:] = torch.randint_like(self.env.episode_length_buf, high=int(self.env.max_episode_length))
+        obs = self.env.get_observations()
+        pobs = self.env.get_privileged_observations()
+        cobs = pobs if pobs is not None else obs
+        obs, cobs = obs.to(self.device), cobs.to(self.device)
+        self.alg.actor_critic.train()
+        rewbuffer, lenbuffer = deque(maxlen=100), deque(maxlen=100)
+        cur_rew = torch.zeros(self.env.num_envs, dtype=torch.float, device=self.device)
+        cur_len = torch.zeros(self.env.num_envs, dtype=torch.float, device=self.device)
+        last = self.current_learning_iteration + num_learning_iterations
+        for it in range(self.current_learning_iteration, last):
+            t0 = time.time()
+            with torch.inference_mode():
+                for _ in range(self.num_steps_per_env):
+                    actions = self.alg.act(obs, cobs)
+                    obs, pobs, rewards, dones, infos = self.env.step(actions)
+                    cobs = pobs if pobs is not None else obs
+                    obs, cobs, rewards, dones = obs.to(self.device), cobs.to(self.device), rewards.to(self.device), dones.to(self.device)
+                    self.alg.process_env_step(rewards, dones, infos)
+                    if self.log_dir is not None:
+                        cur_rew += rewards
+                        cur_len += 1
+                        ids = (dones > 0).nonzero(as_tuple=False)
+                        rewbuffer.extend(cur_rew[ids][:, 0].cpu().numpy().tolist())
+                        lenbuffer.extend(cur_len[ids][:, 0].cpu().numpy().tolist())
+                        cur_rew[ids] = 0
+                        cur_len[ids] = 0
+                t1 = time.time()
+                self.alg.compute_returns(cobs)
+            mean_value_loss, mean_surrogate_loss = self.alg.update()
+            t2 = time.time()
+            self.tot_timesteps += self.num_steps_per_env * self.env.num_envs
+            self.tot_time += t2 - t0
+            if self.log_dir is not None:
+                fps = int(self.num_steps_per_env * self.env.num_envs / (t2 - t0))
+                mr = statistics.mean(rewbuffer) if len(rewbuffer) else float("nan")
+                ml = statistics.mean(lenbuffer) if len(lenbuffer) else float("nan")
+                print(f"it {it}/{last}  steps/s {fps}  collect {t1 - t0:.3f}s  learn {t2 - t1:.3f}s  value_loss {mean_value_loss:.4f}  "
+                      f"surrogate {mean_surrogate_loss:.4f}  std {self.alg.actor_critic.std.mean().item():.3f}  "
+                      f"mean_reward {mr:.3f}  mean_ep_len {ml:.1f}")
+                if it % self.save_interval == 0:
+                    self.save(os.path.join(self.log_dir, f"model_{it}.pt"))
+        self.current_learning_iteration += num_learning_iterations
+        if self.log_dir is not None:
+            self.save(os.path.join(self.log_dir, f"model_{self.current_learning_iteration}.pt"))
+
+    def save(self, path, infos=None):
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        torch.save({"model_state_dict": self.alg.actor_critic.state_dict(),
+                    "optimizer_state_dict": self.alg.optimizer.state_dict(),
+                    "iter": self.current_learning_iteration, "infos": infos}, path)
+
+    def load(self, path, load_optimizer=True):
+        d = torch.load(path, map_location=self.device, weights_only=True)
+        self.alg.actor_critic.load_state_dict(d["model_state_dict"])
+        if load_optimizer:
+            self.alg.optimizer.load_state_dict(d["optimizer_state_dict"])
+        self.current_learning_iteration = d["iter"]
+        return d["infos"]
+
+    def get_inference_policy(self, device=None):
+        self.alg.actor_critic.eval()
+        if device is not None:
+            self.alg.actor_critic.to(device)
+        return self.alg.actor_critic.act_inference

@@ -503,6 +503,10 @@ static void compute_torques_env(const lgo_sim *s, int e, float *tau) {
 }
 
 /* ------------------------------------------------------------------ post-physics (legged_robot.py:106-230, 329-444, 831-969) */
+static float pairwise(float *v, int K) {            /* (v0+v1)+(v2+v3): the butterfly order */
+    for (int stride = 1; stride < K; stride *= 2) for (int k = 0; k + stride < K; k += 2 * stride) v[k] += v[k + stride];
+    return v[0];
+}
 static void resample_commands(const lgo_sim *s, int e, int64_t step, int purpose) {   /* :347-369 */
     const lg_params *P = &s->P;
     float *cmd = s->B.commands + (size_t)e * 4, u[4];
@@ -577,10 +581,7 @@ static void reset_env(const lgo_sim *s, int e, int64_t step) {     /* reset_idx 
     for (int k = 0; k < K; k++) s->B.feet_air_time[(size_t)e * K + k] = 0.0f;
     s->B.episode_length_buf[e] = 0;
     s->B.reset_buf[e] = 1;
-    for (int t = 0; t < P->num_reward_slots; t++) {
-        s->B.episode_sums_done[(size_t)t * N + e] = s->B.episode_sums[(size_t)t * N + e];
-        s->B.episode_sums[(size_t)t * N + e] = 0.0f;
-    }
+    /* extras["episode"] accumulation (:179-183) happens in finish_extras(), in env order */
     if (s->B.sea_hidden_state) for (int l = 0; l < 2; l++) for (int d = 0; d < nd; d++) for (int k = 0; k < 8; k++) {
         size_t i = (((size_t)l * N + e) * nd + d) * 8 + k;
         s->B.sea_hidden_state[i] = 0.0f; s->B.sea_cell_state[i] = 0.0f;
@@ -684,31 +685,46 @@ static void post_physics_env(const lgo_sim *s, int e, int64_t step) {
         float acc = 0.0f; for (int i = 0; i < P->num_height_points; i++) acc += root[2] - mh[i];
         mh_mean = acc / (float)P->num_height_points;
     } else mh_mean = root[2];
-    float s_ar = 0, s_acc = 0, s_lim = 0, s_dv = 0, s_dvl = 0, s_tl = 0, s_tq = 0, s_ss = 0;
-    for (int d = 0; d < nd; d++) {
+    /* sums over joints / bodies / feet: partial per limb, then pairwise (l0+l1)+(l2+l3).  torch.sum's own order is
+     * unspecified; this one is what the limb-per-lane HIP kernel's butterfly produces, so parity can be tight. */
+    float pv[9][LG_MAX_LIMBS];
+    memset(pv, 0, sizeof pv);
+    const int Lc = M->chain_len;
+    for (int k = 0; k < K; k++) for (int j = 0; j < Lc; j++) {
+        int d = k * Lc + j;
         float q = dof[2 * d], qd = dof[2 * d + 1];
-        float da = lact[d] - act[d]; s_ar += da * da;
-        float dd = (ldv[d] - qd) / P->dt_policy; s_acc += dd * dd;
-        float ol = -fminf(q - P->soft_pos_lower[d], 0.0f); ol += fmaxf(q - P->soft_pos_upper[d], 0.0f); s_lim += ol;
-        s_dv += qd * qd;
-        s_dvl += fminf(fmaxf(fabsf(qd) - P->dof_vel_limits[d] * P->soft_dof_vel_limit, 0.0f), 1.0f);
-        s_tl += fmaxf(fabsf(tq[d]) - P->torque_limits[d] * P->soft_torque_limit, 0.0f);
-        s_tq += tq[d] * tq[d];
-        s_ss += fabsf(q - P->default_dof_pos[d]);
+        float da = lact[d] - act[d]; pv[0][k] += da * da;
+        float dd = (ldv[d] - qd) / P->dt_policy; pv[1][k] += dd * dd;
+        float ol = -fminf(q - P->soft_pos_lower[d], 0.0f); ol += fmaxf(q - P->soft_pos_upper[d], 0.0f); pv[2][k] += ol;
+        pv[3][k] += qd * qd;
+        pv[4][k] += fminf(fmaxf(fabsf(qd) - P->dof_vel_limits[d] * P->soft_dof_vel_limit, 0.0f), 1.0f);
+        pv[5][k] += fmaxf(fabsf(tq[d]) - P->torque_limits[d] * P->soft_torque_limit, 0.0f);
+        pv[6][k] += tq[d] * tq[d];
+        pv[7][k] += fabsf(q - P->default_dof_pos[d]);
     }
-    float coll = 0.0f;
-    for (int b = 0; b < nb; b++) if (M->penalised_mask >> b & 1u) {
+    for (int b = 1; b < nb; b++) if (M->penalised_mask >> b & 1u) {     /* limb bodies, grouped by owning limb */
         float n = sqrtf(cf[3 * b] * cf[3 * b] + cf[3 * b + 1] * cf[3 * b + 1] + cf[3 * b + 2] * cf[3 * b + 2]);
+        pv[8][(b - 1) / ((nb - 1) / K)] += (n > 0.1f) ? 1.0f : 0.0f;
+    }
+    float s_ar = pairwise(pv[0], K), s_acc = pairwise(pv[1], K), s_lim = pairwise(pv[2], K), s_dv = pairwise(pv[3], K);
+    float s_dvl = pairwise(pv[4], K), s_tl = pairwise(pv[5], K), s_tq = pairwise(pv[6], K), s_ss = pairwise(pv[7], K);
+    float coll = pairwise(pv[8], K);
+    if (M->penalised_mask & 1u) {
+        float n = sqrtf(cf[0] * cf[0] + cf[1] * cf[1] + cf[2] * cf[2]);
         coll += (n > 0.1f) ? 1.0f : 0.0f;
     }
-    float air = 0.0f, fcf = 0.0f; int stumble = 0, nfly = 0;
+    float air = 0.0f, fcf = 0.0f; int stumble = 0;
+    float fv[3][LG_MAX_LIMBS];
+    memset(fv, 0, sizeof fv);
     for (int k = 0; k < K; k++) {
         const float *f = cf + 3 * M->foot_body[k];
         float fn = sqrtf(f[0] * f[0] + f[1] * f[1] + f[2] * f[2]);
-        fcf += fmaxf(fn - P->max_contact_force, 0.0f);
+        fv[0][k] = fmaxf(fn - P->max_contact_force, 0.0f);
         if (sqrtf(f[0] * f[0] + f[1] * f[1]) > 5.0f * fabsf(f[2])) stumble = 1;
-        nfly += f[2] > 0.1f;
+        fv[1][k] = f[2] > 0.1f ? 1.0f : 0.0f;
     }
+    fcf = pairwise(fv[0], K);
+    float nfly = pairwise(fv[1], K);
     if (sc[LG_REW_FEET_AIR_TIME] != 0.0f) {        /* stateful; only runs when the term is registered (:583-602) */
         for (int k = 0; k < K; k++) {
             const float *f = cf + 3 * M->foot_body[k];
@@ -717,10 +733,10 @@ static void post_physics_env(const lgo_sim *s, int e, int64_t step) {
             *lc = (uint8_t)contact;
             int first = (*at > 0.0f) && filt;
             *at += P->dt_policy;
-            air += (*at - 0.5f) * (first ? 1.0f : 0.0f);
+            fv[2][k] = (*at - 0.5f) * (first ? 1.0f : 0.0f);
             *at *= filt ? 0.0f : 1.0f;
         }
-        air *= (cmd_xy > 0.1f) ? 1.0f : 0.0f;
+        air = pairwise(fv[2], K) * ((cmd_xy > 0.1f) ? 1.0f : 0.0f);
     }
     term[LG_REW_ACTION_RATE] = s_ar;
     term[LG_REW_ANG_VEL_XY] = bav.x * bav.x + bav.y * bav.y;
@@ -733,7 +749,7 @@ static void post_physics_env(const lgo_sim *s, int e, int64_t step) {
     term[LG_REW_FEET_AIR_TIME] = air;
     term[LG_REW_FEET_CONTACT_FORCES] = fcf;
     term[LG_REW_LIN_VEL_Z] = blv.z * blv.z;
-    term[LG_REW_NO_FLY] = (nfly == 1) ? 1.0f : 0.0f;
+    term[LG_REW_NO_FLY] = (nfly == 1.0f) ? 1.0f : 0.0f;
     term[LG_REW_ORIENTATION] = pg.x * pg.x + pg.y * pg.y;
     term[LG_REW_STAND_STILL] = s_ss * ((cmd_xy < 0.1f) ? 1.0f : 0.0f);
     term[LG_REW_STUMBLE] = stumble ? 1.0f : 0.0f;
@@ -760,11 +776,28 @@ static void post_physics_env(const lgo_sim *s, int e, int64_t step) {
     }
     s->B.rew_buf[e] = rew;
 
-    for (int t = 0; t < P->num_reward_slots; t++) s->B.episode_sums_done[(size_t)t * N + e] = 0.0f;
     if (reset) reset_env(s, e, step);                                              /* :128-129 */
     compute_observations_env(s, e, step);                                          /* :130 */
     for (int d = 0; d < nd; d++) { lact[d] = act[d]; ldv[d] = dof[2 * d + 1]; }     /* :132-133 */
     for (int i = 0; i < 6; i++) s->B.last_root_vel[(size_t)e * 6 + i] = root[7 + i]; /* :134 */
+}
+
+/* extras["episode"] (:179-188): mean over the envs whose reset_buf is set of episode_sums / max_episode_length_s,
+ * then zero those sums.  Kept stale when nothing reset (quirk Q4). */
+static void finish_extras(const lgo_sim *s, const uint8_t *mask) {
+    const lg_params *P = &s->P; const int N = P->num_envs, R = P->num_reward_slots;
+    int cnt = 0;
+    for (int e = 0; e < N; e++) cnt += mask[e] ? 1 : 0;
+    if (cnt > 0) for (int t = 0; t < R; t++) {
+        float acc = 0.0f;
+        for (int e = 0; e < N; e++) if (mask[e]) { acc += s->B.episode_sums[(size_t)t * N + e]; s->B.episode_sums[(size_t)t * N + e] = 0.0f; }
+        s->B.episode_means[t] = acc / (float)cnt / P->max_episode_length_s;
+    }
+    if (P->terrain_curriculum && s->B.terrain_levels) {
+        float acc = 0.0f;
+        for (int e = 0; e < N; e++) acc += (float)s->B.terrain_levels[e];
+        s->B.episode_means[R] = acc / (float)N;
+    }
 }
 
 /* ------------------------------------------------------------------ C-ABI */
@@ -803,12 +836,16 @@ int lgo_step(lgo_sim *s, const float *actions, int64_t step, void *stream) {
         }
         post_physics_env(s, e, step);                                                                                           /* :97 */
     }
+    finish_extras(s, s->B.reset_buf);
     return 0;
 }
 
 int lgo_reset_idx(lgo_sim *s, const int32_t *env_ids, int32_t count, int64_t step, void *stream) {
     (void)stream;
-    for (int i = 0; i < count; i++) reset_env(s, env_ids[i], step);
+    uint8_t *mask = (uint8_t *)calloc((size_t)s->P.num_envs, 1);
+    for (int i = 0; i < count; i++) { reset_env(s, env_ids[i], step); mask[env_ids[i]] = 1; }
+    finish_extras(s, mask);
+    free(mask);
     return 0;
 }
 int lgo_compute_observations_only(lgo_sim *s, int64_t step, void *stream) {
