@@ -133,12 +133,24 @@ def main():
         dist.destroy_process_group()
 
 
+def _usable_cores():
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("LG_BENCH_MAX_THREADS", "64"))))
+
+
 def cpu_baseline(a):
     """Time the CPU oracle on the same workload shape (own restatement: PhysX CPU is unavailable)."""
     import numpy as np
     from tests.common import make_setup, grid_origins, randomize_env_params
     from oracle.oracle import OracleSim
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = _usable_cores()
     N = a.num_envs
     cfg, robot, p, names, model, w = make_setup(a.task, N)
     o = OracleSim(p, model, robot, w, threads=cores)

@@ -84,6 +84,44 @@ LG_DEV S6 ai_mul(const AI &I, S6 s) {
     return r;
 }
 
+// U = I (w, 0): the joint motion subspace is a pure rotation about the body's own reference point
+LG_DEV S6 ai_mul_w(const AI &I, V3 w) {
+    S6 r;
+    r.w = symv(I.A, w);
+    r.v = v3(I.H[0] * w.x + I.H[3] * w.y + I.H[6] * w.z, I.H[1] * w.x + I.H[4] * w.y + I.H[7] * w.z,
+             I.H[2] * w.x + I.H[5] * w.y + I.H[8] * w.z);
+    return r;
+}
+// Re-express (I, p) given about point P at Q = P - d:  H' = H + [d]x M,  A' = A + [d]x H^T - H'[d]x,  n' = n + d x f
+LG_DEV void ai_shift(AI &I, S6 &p, V3 d) {
+    const int ix[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
+    float T[9];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        V3 x = cross(d, v3(I.M[ix[0][j]], I.M[ix[1][j]], I.M[ix[2][j]]));
+        T[j] = I.H[j] + x.x; T[3 + j] = I.H[3 + j] + x.y; T[6 + j] = I.H[6 + j] + x.z;
+    }
+    V3 dxh[3], txd[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) dxh[j] = cross(d, v3(I.H[3 * j], I.H[3 * j + 1], I.H[3 * j + 2]));
+#pragma unroll
+    for (int i = 0; i < 3; i++) txd[i] = cross(v3(T[3 * i], T[3 * i + 1], T[3 * i + 2]), d);
+    float A2[6];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = i; j < 3; j++) {
+            float a = (i == 0) ? dxh[j].x : (i == 1) ? dxh[j].y : dxh[j].z;
+            float b = (j == 0) ? txd[i].x : (j == 1) ? txd[i].y : txd[i].z;
+            A2[ix[i][j]] = I.A[ix[i][j]] + a - b;
+        }
+#pragma unroll
+    for (int i = 0; i < 6; i++) I.A[i] = A2[i];
+#pragma unroll
+    for (int i = 0; i < 9; i++) I.H[i] = T[i];
+    p.w = p.w + cross(d, p.v);
+}
+
 // SPD 6x6 solve by LDL^T, fully unrolled (registers only)
 LG_DEV bool solve6(const AI &I, const float *b, float *x) {
     float m[6][6];

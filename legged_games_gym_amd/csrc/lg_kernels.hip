@@ -123,41 +123,9 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, float (&root)[13],
     const V3 grav = v3(P.gravity[0], P.gravity[1], P.gravity[2]);
     const float kn = P.contact_stiffness * dt + P.contact_damping;
 
-    // ---- kinematics (world axes, positions relative to the base origin)
-    const M3 R0 = quat_to_mat(root + 3);
-    const V3 w0 = v3(root[10], root[11], root[12]), v0 = v3(root[7], root[8], root[9]);
-    V3 rb[L], wb[L], vb[L];
-    M3 Rb[L];
-    S6 S[L], C[L];
-#pragma unroll
-    for (int j = 0; j < L; j++) {
-        const float *tj = tab + j * LG_JS;
-        const V3 rpar = j ? rb[j ? j - 1 : 0] : v3(0, 0, 0), wpar = j ? wb[j ? j - 1 : 0] : w0, vpar = j ? vb[j ? j - 1 : 0] : v0;
-        const M3 &Rpar = j ? Rb[j ? j - 1 : 0] : R0;
-        rb[j] = rpar + mul(Rpar, v3(tj[J_POS], tj[J_POS + 1], tj[J_POS + 2]));
-        M3 Rfix;
-#pragma unroll
-        for (int i = 0; i < 9; i++) Rfix.m[i] = tj[J_ROT + i];
-        const M3 Rz = mul(Rpar, Rfix);
-        const V3 ax = mul(Rz, v3(tj[J_AXIS], tj[J_AXIS + 1], tj[J_AXIS + 2]));
-        float sn, cs;
-        sincosf(q[j], &sn, &cs);
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            V3 col = v3(Rz.m[c], Rz.m[3 + c], Rz.m[6 + c]);
-            V3 rot = (col * cs + cross(ax, col) * sn) + ax * (dot(ax, col) * (1.0f - cs));
-            Rb[j].m[c] = rot.x; Rb[j].m[3 + c] = rot.y; Rb[j].m[6 + c] = rot.z;
-        }
-        S[j].w = ax; S[j].v = cross(rb[j], ax);
-        wb[j] = wpar + ax * qd[j];
-        vb[j] = vpar + S[j].v * qd[j];
-        C[j].w = cross(wb[j], S[j].w) * qd[j];
-        C[j].v = (cross(wb[j], S[j].v) + cross(vb[j], S[j].w)) * qd[j];
-    }
-
-    // ---- rigid-body inertia about O and bias force (gyroscopic - gravity) of one body
-    auto body_terms = [&](float m, V3 com_l, const float *Il, const M3 &R, V3 r, V3 w, V3 v, AI &I0, S6 &p0) {
-        V3 c = r + mul(R, com_l);
+    // rigid-body inertia about the body's own reference point and bias force (gyroscopic - gravity)
+    auto body_terms = [&](float m, V3 com_l, const float *Il, const M3 &R, V3 w, V3 v, AI &I0, S6 &p0) {
+        V3 c = mul(R, com_l);
         M3 Ilf; Ilf.m[0] = Il[0]; Ilf.m[1] = Il[1]; Ilf.m[2] = Il[2]; Ilf.m[3] = Il[1]; Ilf.m[4] = Il[3]; Ilf.m[5] = Il[4];
         Ilf.m[6] = Il[2]; Ilf.m[7] = Il[4]; Ilf.m[8] = Il[5];
         M3 Rt;
@@ -178,40 +146,71 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, float (&root)[13],
         p0.w = (cross(w, n) + cross(v, l)) - cross(c, fg);
         p0.v = cross(w, l) - fg;
     };
+
+    // ---- per body, fused: kinematics -> inertia / bias -> contact candidates.  World axes; each body's spatial
+    // quantities live at ITS OWN joint origin O_j (DESIGN.md "Conditioning"): db = O_j - O_parent, wb = angular
+    // velocity, vb = velocity of the body point at O_j, S_j = (ax_j, 0), C_j = velocity-product acceleration.
+    const M3 R0 = quat_to_mat(root + 3);
+    const V3 w0 = v3(root[10], root[11], root[12]), v0 = v3(root[7], root[8], root[9]);
+    V3 db[L], ax[L];
+    S6 C[L];
     AI I0[L], I0b;
     S6 p0[L], p0b;
-#pragma unroll
-    for (int j = 0; j < L; j++) {
-        const float *tj = tab + j * LG_JS;
-        float Il[6];
-#pragma unroll
-        for (int i = 0; i < 6; i++) Il[i] = tj[J_INERTIA + i];
-        body_terms(tj[J_MASS], v3(tj[J_COM], tj[J_COM + 1], tj[J_COM + 2]), Il, Rb[j], rb[j], wb[j], vb[j], I0[j], p0[j]);
-    }
+    Contact cb[NBASE], cl[NPT];
     {
         float sc = base_mass / A.base.mass, Il[6];
 #pragma unroll
         for (int i = 0; i < 6; i++) Il[i] = A.base.inertia[i] * sc;
-        body_terms(base_mass, v3(A.base.com[0], A.base.com[1], A.base.com[2]), Il, R0, v3(0, 0, 0), w0, v0, I0b, p0b);
-    }
-
-    // ---- contact candidates: base points (every lane, redundantly) and this limb's points
-    Contact cb[NBASE], cl[NPT];
+        body_terms(base_mass, v3(A.base.com[0], A.base.com[1], A.base.com[2]), Il, R0, w0, v0, I0b, p0b);
 #pragma unroll
-    for (int i = 0; i < NBASE; i++) {
-        V3 r = mul(R0, v3(A.base.pts[i][0], A.base.pts[i][1], A.base.pts[i][2]));
-        float h; V3 n;
-        ground_query<HF>(A, root[0] + r.x, root[1] + r.y, h, n);
-        contact_setup(cb[i], P, r, n, A.base.pts[i][3] - (root[2] + r.z - h) * n.z, v0 + cross(w0, r));
+        for (int i = 0; i < NBASE; i++) {
+            V3 r = mul(R0, v3(A.base.pts[i][0], A.base.pts[i][1], A.base.pts[i][2]));
+            float h; V3 n;
+            ground_query<HF>(A, root[0] + r.x, root[1] + r.y, h, n);
+            contact_setup(cb[i], P, r, n, A.base.pts[i][3] - (root[2] + r.z - h) * n.z, v0 + cross(w0, r));
+        }
     }
+    {
+        M3 Rpar = R0;
+        V3 rpar = v3(0, 0, 0), wpar = w0, vpar = v0;
 #pragma unroll
-    for (int i = 0; i < NPT; i++) {
-        const int j = T::pt_joint(i);
-        const float *tp = tab + L * LG_JS + 4 * i;
-        V3 r = rb[j] + mul(Rb[j], v3(tp[0], tp[1], tp[2]));
-        float h; V3 n;
-        ground_query<HF>(A, root[0] + r.x, root[1] + r.y, h, n);
-        contact_setup(cl[i], P, r, n, tp[3] - (root[2] + r.z - h) * n.z, vb[j] + cross(wb[j], r));
+        for (int j = 0; j < L; j++) {
+            const float *tj = tab + j * LG_JS;
+            db[j] = mul(Rpar, v3(tj[J_POS], tj[J_POS + 1], tj[J_POS + 2]));
+            const V3 rj = rpar + db[j];
+            M3 Rfix;
+#pragma unroll
+            for (int i = 0; i < 9; i++) Rfix.m[i] = tj[J_ROT + i];
+            const M3 Rz = mul(Rpar, Rfix);
+            ax[j] = mul(Rz, v3(tj[J_AXIS], tj[J_AXIS + 1], tj[J_AXIS + 2]));
+            float sn, cs;
+            sincosf(q[j], &sn, &cs);
+            M3 Rj;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                V3 col = v3(Rz.m[c], Rz.m[3 + c], Rz.m[6 + c]);
+                V3 rot = (col * cs + cross(ax[j], col) * sn) + ax[j] * (dot(ax[j], col) * (1.0f - cs));
+                Rj.m[c] = rot.x; Rj.m[3 + c] = rot.y; Rj.m[6 + c] = rot.z;
+            }
+            const V3 wj = wpar + ax[j] * qd[j];
+            const V3 vj = vpar + cross(wpar, db[j]);
+            C[j].w = cross(wj, ax[j]) * qd[j];
+            C[j].v = cross(vj, ax[j]) * qd[j];
+            float Il[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++) Il[i] = tj[J_INERTIA + i];
+            body_terms(tj[J_MASS], v3(tj[J_COM], tj[J_COM + 1], tj[J_COM + 2]), Il, Rj, wj, vj, I0[j], p0[j]);
+#pragma unroll
+            for (int i = 0; i < NPT; i++) if (T::pt_joint(i) == j) {
+                const float *tp = tab + L * LG_JS + 4 * i;
+                V3 r = mul(Rj, v3(tp[0], tp[1], tp[2]));
+                V3 pw = rj + r;
+                float h; V3 n;
+                ground_query<HF>(A, root[0] + pw.x, root[1] + pw.y, h, n);
+                contact_setup(cl[i], P, r, n, tp[3] - (root[2] + pw.z - h) * n.z, vj + cross(wj, r));
+            }
+            Rpar = Rj; rpar = rj; wpar = wj; vpar = vj;
+        }
     }
 
     // ---- articulated-body passes with the contact impedances folded in
@@ -227,10 +226,10 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, float (&root)[13],
 #pragma unroll
             for (int i = 0; i < NPT; i++) if (T::pt_joint(i) == j) contact_assemble(cl[i], P, kn, IA, pA);
             if (j < L - 1) { ai_add(IA, Ia); pA = pA + pa; }
-            U[j] = ai_mul(IA, S[j]);
+            U[j] = ai_mul_w(IA, ax[j]);
             float damp = tj[J_DAMP];
-            float D = dot(S[j], U[j]) + tj[J_ARM] + dt * damp;
-            float u = tau[j] - dot(S[j], pA) - damp * qd[j];
+            float D = dot(ax[j], U[j].w) + tj[J_ARM] + dt * damp;
+            float u = tau[j] - dot(ax[j], pA.w) - damp * qd[j];
             float lo = tj[J_LO], hi = tj[J_HI];
             if (lo <= hi) {
                 float qp = q[j] + dt * qd[j];
@@ -246,6 +245,7 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, float (&root)[13],
             Ia = IA;
             ai_add_rank1(Ia, -Dinv[j], U[j].w, U[j].v);
             pa = (pA + ai_mul(Ia, C[j])) + U[j] * (u * Dinv[j]);
+            ai_shift(Ia, pa, db[j]);                 // to the parent's origin (the base origin for j == 0)
         }
         group_sum<K>(Ia, pa);                     // (limb0+limb1)+(limb2+limb3) on every lane of the env
         AI IAb = I0b; S6 pAb = p0b;
@@ -261,9 +261,12 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, float (&root)[13],
         S6 a = acc0;
 #pragma unroll
         for (int j = 0; j < L; j++) {
-            S6 ap = a + C[j];
+            S6 ap;
+            ap.w = a.w + C[j].w;
+            ap.v = (a.v + cross(a.w, db[j])) + C[j].v;
             float qdd = (uu[j] - dot(U[j], ap)) * Dinv[j];
-            a = ap + S[j] * qdd;
+            a.w = ap.w + ax[j] * qdd;
+            a.v = ap.v;
             uu[j] = qdd;
 #pragma unroll
             for (int i = 0; i < NPT; i++) if (T::pt_joint(i) == j) contact_evaluate(cl[i], P, kn, mu, a);
@@ -516,6 +519,15 @@ __global__ void __launch_bounds__(LG_BLOCK) k_step(const KArgs A) {
 
     // ---- decimation x (torque -> physics)   legged_robot.py:90-96
     float Frep[NREP][3], Fbase[3];
+    if (P.decimation == 0) {      // post-physics only (parity tests): contact forces / torques are inputs
+        const float *cf = B.contact_forces + ((size_t)e * (1 + K * NREP) + 1 + k * NREP) * 3;
+#pragma unroll
+        for (int r = 0; r < NREP; r++) { Frep[r][0] = cf[3 * r]; Frep[r][1] = cf[3 * r + 1]; Frep[r][2] = cf[3 * r + 2]; }
+        const float *c0 = B.contact_forces + (size_t)e * (1 + K * NREP) * 3;
+        Fbase[0] = c0[0]; Fbase[1] = c0[1]; Fbase[2] = c0[2];
+#pragma unroll
+        for (int j = 0; j < L; j++) tau[j] = B.torques[d0 + j];
+    }
 #pragma unroll 1
     for (int it = 0; it < P.decimation; it++) {
         if (NET) {

@@ -23,7 +23,8 @@ _TORCH_DTYPES = {"float32": torch.float32, "bool": torch.bool, "int64": torch.in
 
 class DeviceSim:
     def __init__(self, params: capi.lg_params, model: capi.lg_robot_model, robot, device: torch.device,
-                 actuator_weights: Optional[np.ndarray] = None):
+                 actuator_weights: Optional[np.ndarray] = None, height_samples: Optional[np.ndarray] = None,
+                 terrain_origins: Optional[np.ndarray] = None):
         device = torch.device(device)
         if device.type != "cuda":
             raise RuntimeError(
@@ -35,7 +36,11 @@ class DeviceSim:
         for name, (shape, dt) in packing.buffer_spec(params, robot).items():
             self.buf[name] = torch.zeros(shape, dtype=_TORCH_DTYPES[dt], device=device)
         self.buf["friction_coeffs"].fill_(1.0)
-        self.rebind()
+        if height_samples is not None:
+            self.set_terrain(height_samples, terrain_origins)
+        elif params.terrain_type != capi.TERRAIN_HEIGHTFIELD:
+            self.rebind()
+        # a height-field sim is bound by the set_terrain() call that must follow
 
     def set_terrain(self, height_samples: np.ndarray, terrain_origins: np.ndarray):
         self.buf["height_samples"] = torch.from_numpy(np.ascontiguousarray(height_samples, dtype=np.int16)).to(self.device)

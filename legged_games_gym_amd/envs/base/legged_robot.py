@@ -136,7 +136,9 @@ class LeggedRobot(BaseTask):
         if self._params.control_type == capi.CTRL["actuator_net"]:
             weights = packing.load_actuator_weights(
                 cfg.control.actuator_net_file.format(LEGGED_GYM_ROOT_DIR=LEGGED_GYM_ROOT_DIR))
-        self._sim = DeviceSim(self._params, self._model, rm, torch.device(self.device), weights)
+        hs = self.terrain.heightsamples if self.terrain is not None else None
+        to = self.terrain.env_origins if self.terrain is not None else None
+        self._sim = DeviceSim(self._params, self._model, rm, torch.device(self.device), weights, hs, to)
         b = self._sim.buf
 
         # body index lookups by substring (:696-702, :733-750)
@@ -176,7 +178,6 @@ class LeggedRobot(BaseTask):
             dm = np.array([np.random.uniform(rng[0], rng[1]) for _ in range(self.num_envs)], dtype=np.float32)
             b["base_mass_delta"].copy_(torch.from_numpy(dm).to(self.device))
         if self.terrain is not None:
-            self._sim.set_terrain(self.terrain.heightsamples, self.terrain.env_origins)
             self.height_samples = self._sim.buf["height_samples"].view(self.terrain.tot_rows, self.terrain.tot_cols)
             b["terrain_levels"].copy_(self.terrain_levels.to(torch.int32))
             b["terrain_types"].copy_(self.terrain_types.to(torch.int32))

@@ -271,6 +271,29 @@ typedef struct {
     v3    f;           /* resulting force (world) */
 } contact_t;
 
+/* Re-express an articulated inertia / force given about point P at the point Q = P - d (d = P - Q):
+ *   I_Q = E^T I_P E,  E = [[1,0],[-[d]x,1]]  ->  H' = H + [d]x M,  A' = A + [d]x H^T - H' [d]x,  M' = M;   n' = n + d x f. */
+static void ai_shift(ai6 *I, sv6 *p, v3 d) {
+    static const int ix[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
+    float T[9], A2[6];
+    for (int j = 0; j < 3; j++) {
+        v3 mc = V(I->M[ix[0][j]], I->M[ix[1][j]], I->M[ix[2][j]]);
+        v3 x = cross(d, mc);
+        T[j] = I->H[j] + x.x; T[3 + j] = I->H[3 + j] + x.y; T[6 + j] = I->H[6 + j] + x.z;
+    }
+    v3 dxh[3], txd[3];          /* dxh[j] = d x row_j(H) ; txd[i] = row_i(T) x d */
+    for (int j = 0; j < 3; j++) dxh[j] = cross(d, V(I->H[3 * j], I->H[3 * j + 1], I->H[3 * j + 2]));
+    for (int i = 0; i < 3; i++) txd[i] = cross(V(T[3 * i], T[3 * i + 1], T[3 * i + 2]), d);
+    for (int i = 0; i < 3; i++) for (int j = i; j < 3; j++) {
+        float a = (i == 0) ? dxh[j].x : (i == 1) ? dxh[j].y : dxh[j].z;
+        float b = (j == 0) ? txd[i].x : (j == 1) ? txd[i].y : txd[i].z;
+        A2[ix[i][j]] = I->A[ix[i][j]] + a - b;
+    }
+    for (int i = 0; i < 6; i++) I->A[i] = A2[i];
+    for (int i = 0; i < 9; i++) I->H[i] = T[i];
+    p->w = add(p->w, cross(d, p->v));
+}
+
 static void physics_substep_env(const lgo_sim *s, int e, const float *tau, int write_contacts) {
     const lg_robot_model *M = &s->R;
     const lg_params *P = &s->P;
@@ -280,33 +303,37 @@ static void physics_substep_env(const lgo_sim *s, int e, const float *tau, int w
     float *dof = s->B.dof_state + (size_t)e * nd * 2;
     const v3 grav = V(P->gravity[0], P->gravity[1], P->gravity[2]);
 
-    /* ---- kinematics: everything in world axes, positions relative to the base origin O */
+    /* ---- kinematics.  World axes throughout; every body's spatial quantities are expressed about ITS OWN
+     * joint origin O_b (the base about its origin), so lever arms stay of the order of a link length and
+     * fp32 does not lose the small distal inertias (DESIGN.md "Conditioning").
+     *   rb = O_b relative to the base origin, db = O_b - O_parent, wb = angular velocity,
+     *   vb = velocity of the body point at O_b, S = (axis, 0), C = velocity-product acceleration. */
     float Rb[NB][9];
-    v3 rb[NB], wb[NB], vb[NB];            /* body origin, angular velocity, velocity of the body point at O */
-    sv6 S[NB], C[NB];                     /* joint motion subspace and velocity-product acceleration */
+    v3 rb[NB], db[NB], wb[NB], vb[NB], ax[NB];
+    sv6 C[NB];
     quat_to_mat(root + 3, Rb[0]);
-    rb[0] = V(0, 0, 0); wb[0] = V(root[10], root[11], root[12]); vb[0] = V(root[7], root[8], root[9]);
+    rb[0] = V(0, 0, 0); db[0] = V(0, 0, 0); wb[0] = V(root[10], root[11], root[12]); vb[0] = V(root[7], root[8], root[9]);
     for (int k = 0; k < K; k++) for (int j = 0; j < L; j++) {
         int d = k * L + j, b = 1 + d, par = (j == 0) ? 0 : b - 1;
         float q = dof[2 * d], qd = dof[2 * d + 1];
-        rb[b] = add(rb[par], mv(Rb[par], V(M->joint_pos[d][0], M->joint_pos[d][1], M->joint_pos[d][2])));
+        db[b] = mv(Rb[par], V(M->joint_pos[d][0], M->joint_pos[d][1], M->joint_pos[d][2]));
+        rb[b] = add(rb[par], db[b]);
         float R0[9];
         mm(Rb[par], M->joint_rot[d], R0);
-        v3 ax = mv(R0, V(M->joint_axis[d][0], M->joint_axis[d][1], M->joint_axis[d][2]));
+        ax[b] = mv(R0, V(M->joint_axis[d][0], M->joint_axis[d][1], M->joint_axis[d][2]));
         float sn = sinf(q), cs = cosf(q);
         for (int c = 0; c < 3; c++) {       /* Rodrigues on each column of R0 about the world axis */
             v3 col = V(R0[c], R0[3 + c], R0[6 + c]);
-            v3 rot = add(add(scl(col, cs), scl(cross(ax, col), sn)), scl(ax, dot(ax, col) * (1.0f - cs)));
+            v3 rot = add(add(scl(col, cs), scl(cross(ax[b], col), sn)), scl(ax[b], dot(ax[b], col) * (1.0f - cs)));
             Rb[b][c] = rot.x; Rb[b][3 + c] = rot.y; Rb[b][6 + c] = rot.z;
         }
-        S[b].w = ax; S[b].v = cross(rb[b], ax);
-        wb[b] = add(wb[par], scl(ax, qd));
-        vb[b] = add(vb[par], scl(S[b].v, qd));
-        C[b].w = scl(cross(wb[b], S[b].w), qd);
-        C[b].v = scl(add(cross(wb[b], S[b].v), cross(vb[b], S[b].w)), qd);
+        wb[b] = add(wb[par], scl(ax[b], qd));
+        vb[b] = add(vb[par], cross(wb[par], db[b]));
+        C[b].w = scl(cross(wb[b], ax[b]), qd);
+        C[b].v = scl(cross(vb[b], ax[b]), qd);
     }
 
-    /* ---- rigid-body inertias about O and bias forces (gyroscopic - gravity) */
+    /* ---- rigid-body inertias about O_b and bias forces (gyroscopic - gravity) */
     ai6 I0[NB];
     sv6 p0[NB];
     for (int b = 0; b <= nd; b++) {
@@ -322,8 +349,7 @@ static void physics_substep_env(const lgo_sim *s, int e, const float *tau, int w
             for (int i = 0; i < 6; i++) Il[i] = M->body_inertia[b - 1][i];
             com = V(M->body_com[b - 1][0], M->body_com[b - 1][1], M->body_com[b - 1][2]);
         }
-        v3 c = add(rb[b], mv(Rb[b], com));
-        /* Ic = R Il R^T */
+        v3 c = mv(Rb[b], com);
         float Ilf[9] = {Il[0], Il[1], Il[2], Il[1], Il[3], Il[4], Il[2], Il[4], Il[5]}, T[9], Rt[9], Ic[9];
         mm(Rb[b], Ilf, T);
         for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Rt[3 * i + j] = Rb[b][3 * j + i];
@@ -338,7 +364,7 @@ static void physics_substep_env(const lgo_sim *s, int e, const float *tau, int w
         p0[b].v = sub(cross(wb[b], l), fg);
     }
 
-    /* ---- contact candidates */
+    /* ---- contact candidates (r is relative to the carrying body's O_b) */
     contact_t ct[NPTS];
     int nc = 0;
     float mu_env = 0.5f * ((s->B.friction_coeffs ? s->B.friction_coeffs[e] : 1.0f) + P->ground_friction);
@@ -349,10 +375,11 @@ static void physics_substep_env(const lgo_sim *s, int e, const float *tau, int w
             int b = (g < 0) ? 0 : 1 + g * L + pt->joint;
             contact_t *c = &ct[nc];
             c->body = b; c->report = pt->report_body;
-            c->r = add(rb[b], mv(Rb[b], V(pt->pos[0], pt->pos[1], pt->pos[2])));
+            c->r = mv(Rb[b], V(pt->pos[0], pt->pos[1], pt->pos[2]));
+            v3 pw = add(rb[b], c->r);
             float h;
-            ground_query(s, root[0] + c->r.x, root[1] + c->r.y, &h, &c->n);
-            c->depth = pt->radius - (root[2] + c->r.z - h) * c->n.z;
+            ground_query(s, root[0] + pw.x, root[1] + pw.y, &h, &c->n);
+            c->depth = pt->radius - (root[2] + pw.z - h) * c->n.z;
             c->on = c->depth > -P->contact_margin;
             c->vc = add(vb[b], cross(wb[b], c->r));
             c->kn = P->contact_stiffness * dt + P->contact_damping;
@@ -382,9 +409,10 @@ static void physics_substep_env(const lgo_sim *s, int e, const float *tau, int w
         for (int k = 0; k < K; k++) for (int j = L - 1; j >= 0; j--) {
             int d = k * L + j, b = 1 + d, par = (j == 0) ? 0 : b - 1;
             float q = dof[2 * d], qd = dof[2 * d + 1];
-            U[b] = ai_mul(&IA[b], S[b]);
-            float D = sdot(S[b], U[b]) + M->dof_armature[d] + dt * M->dof_damping[d];
-            float u = tau[d] - sdot(S[b], pA[b]) - M->dof_damping[d] * qd;
+            sv6 Sb = {ax[b], V(0, 0, 0)};
+            U[b] = ai_mul(&IA[b], Sb);
+            float D = dot(ax[b], U[b].w) + M->dof_armature[d] + dt * M->dof_damping[d];
+            float u = tau[d] - dot(ax[b], pA[b].w) - M->dof_damping[d] * qd;
             if (M->dof_lower[d] <= M->dof_upper[d]) {       /* implicit joint-limit spring-damper */
                 /* active when the explicit prediction leaves [lower, upper]:
                  * tau_l = -k (q' - lim) - b qd'  with q' = q + dt qd', qd' = qd + dt qdd */
@@ -398,17 +426,15 @@ static void physics_substep_env(const lgo_sim *s, int e, const float *tau, int w
                 }
             }
             Dinv[b] = 1.0f / D; uu[b] = u;
-            /* Ia = IA - U U^T / D ; pa = pA + Ia c + U u / D ; accumulate on the parent */
+            /* Ia = IA - U U^T / D ; pa = pA + Ia c + U u / D ; shift to the parent's origin ; accumulate */
             ai6 Ia = IA[b];
             ai_add_rank1(&Ia, -Dinv[b], U[b].w, U[b].v);
             sv6 pa = sadd(sadd(pA[b], ai_mul(&Ia, C[b])), sscl(U[b], u * Dinv[b]));
+            ai_shift(&Ia, &pa, db[b]);
             if (par != 0) { ai_add(&IA[par], &Ia); pA[par] = sadd(pA[par], pa); }
-            else {
-                /* base accumulation happens in a fixed pairwise order (mirrors the quad-lane butterfly of the HIP kernel) */
-                IA[b] = Ia; pA[b] = pa;     /* stash on the first body of the limb */
-            }
+            else { IA[b] = Ia; pA[b] = pa; }      /* stash: the base sums limbs pairwise (mirrors the HIP butterfly) */
         }
-        {   /* base: I0 + contacts (already in IA[0]) + sum over limbs, pairwise (0+1)+(2+3) */
+        {   /* base: (I0 + contacts) + ((l0+l1)+(l2+l3)) */
             ai6 acc_I[LG_MAX_LIMBS]; sv6 acc_p[LG_MAX_LIMBS];
             for (int k = 0; k < K; k++) { acc_I[k] = IA[1 + k * L]; acc_p[k] = pA[1 + k * L]; }
             for (int stride = 1; stride < K; stride *= 2)
@@ -420,9 +446,12 @@ static void physics_substep_env(const lgo_sim *s, int e, const float *tau, int w
         acc[0].w = V(a0[0], a0[1], a0[2]); acc[0].v = V(a0[3], a0[4], a0[5]);
         for (int k = 0; k < K; k++) for (int j = 0; j < L; j++) {
             int b = 1 + k * L + j, par = (j == 0) ? 0 : b - 1;
-            sv6 ap = sadd(acc[par], C[b]);
+            sv6 ap;                                   /* parent's acceleration re-expressed at O_b, plus C */
+            ap.w = add(acc[par].w, C[b].w);
+            ap.v = add(add(acc[par].v, cross(acc[par].w, db[b])), C[b].v);
             float qdd = (uu[b] - sdot(U[b], ap)) * Dinv[b];
-            acc[b] = sadd(ap, sscl(S[b], qdd));
+            acc[b].w = add(ap.w, scl(ax[b], qdd));
+            acc[b].v = ap.v;
             uu[b] = qdd;                 /* reuse: joint acceleration */
         }
         /* evaluate contacts at the end-of-step velocity and (re)classify */

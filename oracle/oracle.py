@@ -54,7 +54,8 @@ class OracleSim:
             self.buf[name] = np.zeros(shape, dtype=np.dtype(dt) if dt != "bool" else np.uint8)
         self.buf["friction_coeffs"][:] = 1.0
         self.extra: Dict[str, np.ndarray] = {}
-        self.rebind()
+        if params.terrain_type != capi.TERRAIN_HEIGHTFIELD:
+            self.rebind()           # a height-field sim is bound by the set_terrain() call that must follow
 
     def set_terrain(self, height_samples: np.ndarray, terrain_origins: np.ndarray):
         self.extra["height_samples"] = np.ascontiguousarray(height_samples, dtype=np.int16)

@@ -1,0 +1,271 @@
+"""-m gpu: the HIP path (through the C-ABI) against the CPU oracle on identical seeded inputs, against the
+committed golden fixtures, and -- at BASELINE.json's full size -- against size-independent physical invariants.
+
+Tolerances (fp32, stated per test): integer / boolean outputs and everything that involves no physics are
+compared exactly or to 1e-6; one policy step (4 rigid-body sub-steps with stiff implicit contacts) to ~1e-3 on
+velocities; trajectories diverge chaotically through contacts, so multi-step checks use standing robots and
+statistical / invariant properties.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.common import make_setup, grid_origins, randomize_env_params
+from tests.test_oracle_torch_side import synth_state
+
+pytestmark = pytest.mark.gpu
+
+
+def pair(task, N, tweak=None, terrain=None, plane=None, decimation=None, seed=1):
+    from oracle.oracle import OracleSim
+    from legged_games_gym_amd.device_sim import DeviceSim
+    cfg, robot, p, names, model, w = make_setup(task, N, seed=seed, tweak=tweak, terrain=terrain, plane=plane)
+    if decimation is not None:
+        p.decimation = decimation
+    o = OracleSim(p, model, robot, w, threads=8)
+    d = DeviceSim(p, model, robot, torch.device("cuda:0"), w)
+    if terrain is not None:
+        o.set_terrain(terrain.heightsamples, terrain.env_origins)
+        d.set_terrain(terrain.heightsamples, terrain.env_origins)
+    return cfg, robot, p, names, o, d
+
+
+def put(o, d, name, val):
+    o.buf[name][...] = np.asarray(val).astype(o.buf[name].dtype).reshape(o.buf[name].shape)
+    d.buf[name].copy_(torch.from_numpy(o.buf[name]).to(d.buf[name].dtype).view(d.buf[name].shape))
+
+
+def get(d, name):
+    torch.cuda.synchronize()
+    t = d.buf[name]
+    return (t.to(torch.uint8) if t.dtype == torch.bool else t).cpu().numpy()
+
+
+def maxdiff(o, d, name):
+    return float(np.abs(o.buf[name].astype(np.float64) - get(d, name).astype(np.float64)).max())
+
+
+def init_both(o, d, N, seed=3, origins=None):
+    fr, dm = randomize_env_params(N, seed)
+    put(o, d, "env_origins", grid_origins(N) if origins is None else origins)
+    put(o, d, "friction_coeffs", fr)
+    put(o, d, "base_mass_delta", dm)
+    ids = np.arange(N, dtype=np.int32)
+    o.reset_idx(ids, 0)
+    d.reset_idx(torch.from_numpy(ids), 0)
+
+
+@pytest.mark.parametrize("task", ["anymal_c_flat", "cassie"])
+def test_reset_is_bit_exact(task):
+    N = 130                                       # not a multiple of the wave's env count: exercises the tail
+    cfg, robot, p, names, o, d = pair(task, N)
+    init_both(o, d, N)
+    for k in ("root_states", "dof_state", "commands", "last_actions", "last_dof_vel", "feet_air_time", "episode_length_buf"):
+        assert maxdiff(o, d, k) <= (5e-7 if k == "commands" else 0.0), k      # urange() contracts to one fma on the GPU: 1 ulp
+    assert get(d, "reset_buf").all()
+    # subset reset leaves the others untouched
+    before = get(d, "dof_state").copy()
+    ids = np.array([1, 5, 64, 129], dtype=np.int32)
+    o.reset_idx(ids, 7); d.reset_idx(torch.from_numpy(ids), 7)
+    after = get(d, "dof_state").reshape(N, 12, 2)
+    keep = np.setdiff1d(np.arange(N), ids)
+    assert np.array_equal(after[keep], before.reshape(N, 12, 2)[keep]) and maxdiff(o, d, "dof_state") == 0.0
+
+
+@pytest.mark.parametrize("task", ["anymal_c_flat", "cassie", "anymal_c_rough"])
+def test_post_physics_block_parity(task):
+    """decimation=0: termination, all reward terms, predicated reset, observations, bookkeeping -- no physics."""
+    N = 300
+
+    def tweak(cfg):
+        if task == "anymal_c_rough":
+            for k in ("base_height", "dof_vel", "stand_still", "orientation", "feet_contact_forces", "dof_pos_limits", "termination"):
+                setattr(cfg.rewards.scales, k, -0.37)
+            cfg.rewards.scales.dof_vel_limits, cfg.rewards.scales.torque_limits = -0.11, -0.013
+            cfg.rewards.scales.stumble, cfg.rewards.scales.no_fly = -0.4, 0.21
+            cfg.rewards.only_positive_rewards = False
+    cfg, robot, p, names, o, d = pair(task, N, tweak=tweak, decimation=0)
+    put(o, d, "env_origins", grid_origins(N))
+    st = synth_state(robot, p, N, seed=11)
+    st["episode_length_buf"][::7] = 199            # hits the command-resampling interval after the increment
+    for k, v in st.items():
+        put(o, d, k, v.numpy())
+    act = st["actions"] * 60.0                     # some beyond clip_actions=100
+    for step in (750, 751):                        # 750: push step
+        o.step(act.numpy(), step)
+        d.step(act.cuda(), step)
+        assert np.array_equal(o.buf["reset_buf"], get(d, "reset_buf")) and np.array_equal(o.buf["time_out_buf"], get(d, "time_out_buf"))
+        assert np.array_equal(o.buf["episode_length_buf"], get(d, "episode_length_buf"))
+        assert np.array_equal(o.buf["last_contacts"], get(d, "last_contacts"))
+        for k, tol in (("rew_buf", 3e-6), ("obs_buf", 3e-6), ("commands", 1e-6), ("root_states", 1e-6), ("dof_state", 0.0),
+                       ("feet_air_time", 1e-7), ("episode_sums", 3e-6), ("episode_means", 1e-6), ("last_actions", 0.0),
+                       ("last_dof_vel", 0.0), ("base_lin_vel", 1e-6), ("projected_gravity", 1e-6), ("actions", 0.0), ("last_root_vel", 1e-6)):
+            assert maxdiff(o, d, k) <= tol, (k, step, maxdiff(o, d, k))
+        if "sea_hidden_state" in o.buf:
+            assert maxdiff(o, d, "sea_hidden_state") == 0.0
+    assert o.buf["reset_buf"].sum() > 5
+
+
+def test_actuator_kernel_matches_golden_and_oracle(golden_dir):
+    g = np.load(os.path.join(golden_dir, "actuator_net.npz"))
+    cfg, robot, p, names, o, d = pair("anymal_c_flat", 4)
+    T, R = g["xs"].shape[:2]
+    h = torch.zeros(2, R, 8, device="cuda"); c = torch.zeros(2, R, 8, device="cuda")
+    worst = 0.0
+    for t in range(T):
+        if t == int(g["reset_step"]):
+            h[:, ::int(g["reset_stride"])] = 0; c[:, ::int(g["reset_stride"])] = 0
+        tau = d.actuator_forward(torch.from_numpy(g["xs"][t, :, 0, 0]), torch.from_numpy(g["xs"][t, :, 0, 1]), h, c)
+        worst = max(worst, float(np.abs(tau.cpu().numpy() - g["tau"][t]).max()))
+        assert np.abs(h.cpu().numpy() - g["h"][t]).max() < 5e-6
+    assert worst < 2e-4, worst                    # torques of magnitude ~30 Nm: < 1e-5 relative to the reference net
+    probe = d.actuator_forward(torch.from_numpy(g["probe_x"][:, 0, 0]), torch.from_numpy(g["probe_x"][:, 0, 1]),
+                               torch.zeros(2, 24, 8, device="cuda"), torch.zeros(2, 24, 8, device="cuda"))
+    np.testing.assert_allclose(probe.cpu().numpy()[:4], g["survey_probe_first4"], atol=1e-4)
+
+
+@pytest.mark.parametrize("task", ["anymal_c_flat", "cassie"])
+def test_physics_substep_parity(task):
+    """One 5 ms rigid-body step from random states (airborne, touching and penetrating), given torques."""
+    N = 512
+    cfg, robot, p, names, o, d = pair(task, N)
+    init_both(o, d, N)
+    rng = np.random.default_rng(2)
+    root = o.buf["root_states"].copy()
+    root[:, 2] = rng.uniform(0.35, 0.75, N) if task != "cassie" else rng.uniform(0.7, 1.1, N)
+    quat = np.array([0, 0, 0, 1.0]) + rng.normal(0, 0.15, (N, 4)); quat /= np.linalg.norm(quat, axis=1, keepdims=True)
+    root[:, 3:7] = quat
+    root[:, 7:13] = rng.normal(0, 0.7, (N, 6))
+    put(o, d, "root_states", root)
+    dof = o.buf["dof_state"].copy(); dof[:, 1] = rng.normal(0, 2.0, dof.shape[0])
+    put(o, d, "dof_state", dof)
+    tau = rng.normal(0, 20.0, (N, 12)).astype(np.float32)
+    qd0 = dof.reshape(N, 12, 2)[..., 1].copy()
+    v0 = root[:, 7:13].copy()
+    o.physics_substep(tau, True)
+    d.physics_substep(torch.from_numpy(tau), True)
+    q_o, q_d = o.buf["dof_state"].reshape(N, 12, 2), get(d, "dof_state").reshape(N, 12, 2)
+    # Tolerance relative to how violently each env was accelerated: the random states include multi-centimetre
+    # penetrations (tens of kN through the 1e6 N/m contact), where fp32 rounding of the stiff solve scales with the force.
+    dqd = np.abs(q_o[..., 1] - qd0).max(axis=1)                          # up to ~25 rad/s in one 5 ms step
+    err_v = np.abs(q_o[..., 1] - q_d[..., 1]).max(axis=1)
+    assert (err_v <= 1e-4 * (1.0 + dqd)).all(), float((err_v / (1.0 + dqd)).max())
+    assert np.abs(q_o[..., 0] - q_d[..., 0]).max() < 2e-5               # dof_pos [rad]
+    r_o, r_d = o.buf["root_states"], get(d, "root_states")
+    dv = np.abs(r_o[:, 7:13] - v0).max(axis=1)
+    assert (np.abs(r_o - r_d).max(axis=1) <= 1e-4 * (1.0 + dv)).all()
+    cf_o, cf_d = o.buf["contact_forces"], get(d, "contact_forces")
+    assert (np.abs(cf_o).sum(axis=(1, 2)) > 1).sum() > N // 10            # contacts did occur
+    assert np.abs(cf_o - cf_d).max() < 2e-4 * max(1.0, np.abs(cf_o).max()) + 0.5
+    quiet = np.abs(cf_o).max(axis=(1, 2)) < 1e-9                           # airborne envs: pure ABA, fp32-level agreement
+    assert quiet.sum() > 20 and (err_v[quiet] <= 2e-5 * (1.0 + dqd[quiet])).all()
+
+
+@pytest.mark.parametrize("task,plane", [("anymal_c_flat", True), ("cassie", True)])
+def test_full_step_parity(task, plane):
+    """One fused policy step (clip, 4 x (torque, physics), post-physics) and a short standing trajectory."""
+    N = 256
+    cfg, robot, p, names, o, d = pair(task, N)
+    init_both(o, d, N)
+    g = torch.Generator().manual_seed(0)
+    act = (torch.randn(N, 12, generator=g) * 0.5).float()
+    o.step(act.numpy(), 1); d.step(act.cuda(), 1)
+    q_o, q_d = o.buf["dof_state"].reshape(N, 12, 2), get(d, "dof_state").reshape(N, 12, 2)
+    assert np.abs(q_o[..., 0] - q_d[..., 0]).max() < 1e-4
+    assert np.abs(q_o[..., 1] - q_d[..., 1]).max() < 1e-2
+    assert np.abs(o.buf["root_states"][:, :7] - get(d, "root_states")[:, :7]).max() < 1e-4
+    assert maxdiff(o, d, "rew_buf") < 1e-4 and maxdiff(o, d, "obs_buf") < 2e-3
+    assert np.array_equal(o.buf["reset_buf"], get(d, "reset_buf"))
+    if task == "anymal_c_flat":     # quadruped stands: 25 zero-action steps stay close (no contact switching)
+        z = torch.zeros(N, 12)
+        for it in range(2, 27):
+            o.step(z.numpy(), it); d.step(z.cuda(), it)
+        ok = (o.buf["episode_length_buf"] == get(d, "episode_length_buf"))
+        q_o, q_d = o.buf["dof_state"].reshape(N, 12, 2)[ok], get(d, "dof_state").reshape(N, 12, 2)[ok]
+        err = np.abs(q_o[..., 0] - q_d[..., 0]).max(axis=1)
+        assert ok.mean() > 0.95 and np.median(err) < 2e-3 and np.quantile(err, 0.9) < 2e-2, (ok.mean(), np.median(err), np.quantile(err, 0.9))
+
+
+def _rough_terrain(N):
+    from legged_games_gym_amd.utils.terrain import Terrain
+    from legged_games_gym_amd.envs import configs
+    tc = configs.AnymalCRoughCfg().terrain
+    tc.mesh_type, tc.num_rows, tc.num_cols, tc.border_size = "heightfield", 4, 5, 5
+    np.random.seed(7)
+    return Terrain(tc, N)
+
+
+def test_rough_terrain_step_parity():
+    N = 200
+    terr = _rough_terrain(N)
+
+    def tweak(cfg):
+        cfg.terrain.mesh_type, cfg.terrain.num_rows, cfg.terrain.num_cols, cfg.terrain.border_size = "heightfield", 4, 5, 5
+    cfg, robot, p, names, o, d = pair("anymal_c_rough", N, tweak=tweak, terrain=terr, plane=False)
+    rng = np.random.default_rng(0)
+    lv = rng.integers(0, 4, N).astype(np.int32); ty = (np.arange(N) * 5 // N).astype(np.int32)
+    put(o, d, "terrain_levels", lv); put(o, d, "terrain_types", ty)
+    init_both(o, d, N, origins=terr.env_origins[lv, ty].astype(np.float32))
+    act = (torch.randn(N, 12, generator=torch.Generator().manual_seed(1)) * 0.3).float()
+    for it in (1, 2, 3):
+        o.step(act.numpy(), it); d.step(act.cuda(), it)
+    mh_o, mh_d = o.buf["measured_heights"], get(d, "measured_heights")
+    assert (np.abs(mh_o - mh_d) > 1e-6).mean() < 5e-3 and np.abs(mh_o).max() > 0.05
+    q_o, q_d = o.buf["dof_state"].reshape(N, 12, 2), get(d, "dof_state").reshape(N, 12, 2)
+    assert np.quantile(np.abs(q_o[..., 0] - q_d[..., 0]).max(axis=1), 0.9) < 1e-3
+    assert np.array_equal(o.buf["terrain_levels"], get(d, "terrain_levels"))
+
+
+def test_zero_action_run_like_reference_test_env():
+    """reference legged_gym/tests/test_env.py:42-52 with assertions: zero actions, many steps, nothing explodes,
+    the quadruped keeps standing, net foot force carries the weight, episodes time out at 1000 steps."""
+    N = 64
+    cfg, robot, p, names, o, d = pair("anymal_c_flat", N, tweak=lambda c: (setattr(c.domain_rand, "push_robots", False)))
+    init_both(o, d, N)
+    z = torch.zeros(N, 12, device="cuda")
+    timeouts = 0
+    for it in range(1, 1103):
+        d.step(z, it)
+        if it % 100 == 0 or it > 995:
+            timeouts += int(get(d, "time_out_buf").sum())
+            assert np.isfinite(get(d, "root_states")).all() and np.isfinite(get(d, "obs_buf")).all()
+    assert timeouts >= N * 0.9                                  # (almost) every env reached the 1000-step time-out
+    pg = get(d, "projected_gravity")
+    assert (pg[:, 2] < -0.95).mean() > 0.9                      # upright
+    fz = get(d, "contact_forces")[:, :, 2].sum(axis=1)
+    mass = robot.total_mass + get(d, "base_mass_delta")
+    standing = pg[:, 2] < -0.95
+    np.testing.assert_allclose(fz[standing], (mass * 9.81)[standing], rtol=0.03)
+
+
+def test_full_size_invariants_4096():
+    """BASELINE.json configs[1] size: 4096 envs.  Size-independent properties: bounded state, weight carried by
+    contact forces for upright robots, quaternions stay unit, time-outs/ resets re-initialise into the legal box."""
+    N = 4096
+    from legged_games_gym_amd.device_sim import DeviceSim
+    cfg, robot, p, names, model, w = make_setup("anymal_c_flat", N)
+    d = DeviceSim(p, model, robot, torch.device("cuda:0"), w)
+    fr, dm = randomize_env_params(N, 5)
+    d.buf["env_origins"].copy_(torch.from_numpy(grid_origins(N)))
+    d.buf["friction_coeffs"].copy_(torch.from_numpy(fr)); d.buf["base_mass_delta"].copy_(torch.from_numpy(dm))
+    d.reset_idx(torch.arange(N, dtype=torch.int32), 0)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    resets = 0
+    for it in range(1, 201):
+        a = torch.randn(N, 12, device="cuda", generator=g) * (1.0 if it <= 120 else 0.0)     # flail, then settle
+        d.step(a, it)
+        resets += int(d.buf["reset_buf"].sum())
+    root, dof = get(d, "root_states"), get(d, "dof_state").reshape(N, 12, 2)
+    assert np.isfinite(root).all() and np.isfinite(dof).all() and np.isfinite(get(d, "obs_buf")).all()
+    np.testing.assert_allclose(np.linalg.norm(root[:, 3:7], axis=1), 1.0, atol=1e-5)
+    assert np.abs(dof[..., 1]).max() <= 20.0 + 1e-3                        # URDF velocity limit
+    assert resets > 0
+    pg = get(d, "projected_gravity")
+    up = (pg[:, 2] < -0.97) & (np.abs(root[:, 9]) < 0.05) & (get(d, "episode_length_buf") > 60)
+    assert up.mean() > 0.3
+    fz = get(d, "contact_forces")[:, :, 2].sum(axis=1)
+    mass = robot.total_mass + dm
+    assert np.median(np.abs(fz[up] / (mass[up] * 9.81) - 1.0)) < 0.02
+    assert np.abs(get(d, "obs_buf")).max() <= 100.0
