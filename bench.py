@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--num-envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one captured HIP graph per step")
+    ap.add_argument("--event-steps", type=int, default=200, help="eager steps timed with HIP events for the roofline object")
     a = ap.parse_args()
 
     import torch
@@ -72,33 +74,37 @@ def main():
     with contextlib.redirect_stdout(io.StringIO()):
         obs, _ = env.reset()
 
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
-
-    def one_step(obs, pair=None):
-        actions = policy.act(obs)
-        if pair is not None:
-            pair[0].record()
-        obs, _, _, _, _ = env.step(actions)               # the full VecEnv step (one lg_step call)
-        if pair is not None:
-            pair[1].record()
-        return obs
-
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
     with torch.inference_mode():
+        if a.no_graph:
+            def one_step():
+                env.step(policy.act(env.obs_buf))             # the full VecEnv step (one lg_step call)
+        else:
+            one_step = env.make_graphed_step(policy.act)      # policy forward + sampling + lg_step in ONE HIP graph
         for _ in range(a.warmup):
-            obs = one_step(obs)
+            one_step()
         sync()
         t0 = time.perf_counter()
         for i in range(a.steps):
-            obs = one_step(obs, ev[i])
+            one_step()
         sync()
         elapsed = time.perf_counter() - t0
+        # roofline: duration of the fused step kernel from HIP events recorded on the launch stream around eager
+        # lg_step launches of the SAME rollout, directly after the timed region (a graph replay cannot host events)
+        n_ev = max(1, min(a.event_steps, a.steps))
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
+        for s_, e_ in ev:
+            actions = policy.act(env.obs_buf)
+            s_.record()
+            env.step(actions)
+            e_.record()
+        torch.cuda.synchronize()
     finite = bool(torch.isfinite(env.obs_buf).all()) and bool(torch.isfinite(env.root_states).all())
-    kern_ms = sum(s.elapsed_time(e) for s, e in ev) / max(a.steps, 1)
+    kern_ms = sum(s_.elapsed_time(e_) for s_, e_ in ev) / n_ev
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -119,10 +125,12 @@ def main():
                                    f"{[env.num_obs] + list(pol['actor_hidden_dims']) + [env.num_actions]} rollout (act = mu + sigma*eps), "
                                    "fixed command (0.5,0,0), obs noise + friction/mass randomisation + pushes on",
                        "envs_per_gpu": a.num_envs, "decimation": int(env.cfg.control.decimation), "sim_dt": float(env.sim_params.dt),
-                       "parallelism": f"env-sharded x{world}", "state_finite": finite},
+                       "parallelism": f"env-sharded x{world}", "state_finite": finite,
+                       "launch": "eager" if a.no_graph else "one captured HIP graph per policy step (torch policy ops + lg_step)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel": "k_step<AnymalTraits,NET,plane>" if a.task != "cassie" else "k_step<CassieTraits>",
-                         "kernel_ms": kern_ms, "algorithmic_bytes_per_env_step": bpe,
+                         "kernel_ms": kern_ms, "kernel_ms_method": f"HIP events around {n_ev} eager lg_step launches (k_step + k_extras) right after the timed region",
+                         "algorithmic_bytes_per_env_step": bpe,
                          "note": "fused step is VALU/latency-bound at 4096 envs (256 waves on 1024 SIMDs); see DESIGN.md"},
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LG_ABI_VERSION        4
+#define LG_ABI_VERSION        5
 
 #define LG_MAX_LIMBS          4
 #define LG_MAX_CHAIN          6
@@ -140,6 +140,8 @@ typedef struct lg_buffers {
                                    envs that reset in the latest step that had resets (legged_robot.py:179-183), stale
                                    otherwise; last entry = mean terrain level (:186) */
     float   *extras_accum;      /* [num_reward_slots+1] scratch: per-step sums + count, zeroed by the library */
+    int64_t *step_counter;      /* [1] device copy of common_step_counter (legged_robot.py:115); lets a captured HIP graph
+                                   replay lg_step without new kernel arguments (pass common_step_counter = -1) */
     float   *env_origins;       /* [N,3] */
     int32_t *terrain_levels, *terrain_types;                    /* [N] or NULL           T9 */
     const float   *terrain_origins;   /* [rows,cols,3] or NULL */
@@ -165,7 +167,9 @@ int  lg_bind(lg_sim *sim, const lg_buffers *buffers);
  *   simulate -> refresh_dof_state); post_physics_step (incl. reset_idx for
  *   terminated envs and compute_observations); clip obs.
  * `actions` is [N,ndof] on the device.  `common_step_counter` is the value
- * AFTER the increment of legged_robot.py:115.  Asynchronous on `stream`. */
+ * AFTER the increment of legged_robot.py:115, or -1 to use (device step_counter + 1): the
+ * library stores the value it used back into step_counter, so graph replays self-advance.
+ * Asynchronous on `stream`. */
 int  lg_step(lg_sim *sim, const float *actions, int64_t common_step_counter, void *stream);
 
 /* reset_idx on an explicit env list (base_task.py:114-118 reset(); device int32 ids). */

@@ -16,7 +16,7 @@ from typing import Dict, Optional
 
 import numpy as np
 
-LG_ABI_VERSION = 4
+LG_ABI_VERSION = 5
 LG_MAX_LIMBS, LG_MAX_CHAIN, LG_MAX_DOF = 4, 6, 12
 LG_MAX_LIMB_POINTS, LG_MAX_BASE_POINTS, LG_MAX_BODIES = 8, 4, 20
 LG_MAX_HEIGHT_POINTS, LG_ACTUATOR_FLOATS = 192, 972
@@ -94,7 +94,7 @@ class lg_buffers(C.Structure):
         ("last_root_vel", _PF), ("commands", _PF), ("feet_air_time", _PF), ("last_contacts", _PU8),
         ("base_lin_vel", _PF), ("base_ang_vel", _PF), ("projected_gravity", _PF),
         ("measured_heights", _PF), ("sea_hidden_state", _PF), ("sea_cell_state", _PF),
-        ("episode_sums", _PF), ("episode_means", _PF), ("extras_accum", _PF), ("env_origins", _PF),
+        ("episode_sums", _PF), ("episode_means", _PF), ("extras_accum", _PF), ("step_counter", _PI64), ("env_origins", _PF),
         ("terrain_levels", _PI32), ("terrain_types", _PI32), ("terrain_origins", _PF),
         ("height_samples", _PI16), ("friction_coeffs", _PF), ("base_mass_delta", _PF),
     ]

@@ -229,49 +229,82 @@ LG_DEV void rand4(uint64_t seed, int env, int64_t step, int purpose, int block, 
 }
 LG_DEV float urange(float lo, float hi, float u) { return (hi - lo) * u + lo; }
 
-// ------------------------------------------------------------------ ANYdrive actuator net (anymal.py:71-78)
-// Weights are read through the constant address space so every weight is an
-// SGPR operand of a v_fma (scalar loads, no VGPR / LDS traffic).
-typedef const float __attribute__((address_space(4))) *cfp;
+// ------------------------------------------------------------------ ANYdrive actuator net (anymal.py:71-78) on the matrix cores
+// TorchScript LSTMsea: x*in_scale -> LSTM(2,8,2 layers; gates i,f,g,o) -> out_scale*Linear(8,1), one row per joint.
+//
+// MFMA mapping (v_mfma_f32_32x32x2_f32, exact fp32 fma chains): D[gate 0..31][batch col] += A[gate][k] * B[k][col].
+//  * A = weights: lane l holds W[gate = l&31][k-th input of the step, k = l>>5]; 15 VGPRs hold the whole net
+//    (bias rides along as a K-step against the constant 1).
+//  * The batch is the wave itself: 64 lanes = 64 joint rows, processed as two 32-column groups g (lanes 32g..32g+31).
+//  * Hidden/cell vectors live "unit-split": register s of group g holds unit s of row (32g + l) on lanes l < 32 and
+//    unit s+4 of row (32g + l - 32) on lanes l >= 32.  That is exactly the D layout the MFMA produces (lanes < 32 get
+//    gate rows {0-3, 8-11, 16-19, 24-27} = i,f,g,o of units 0-3, lanes >= 32 units 4-7) AND the B layout the next
+//    MFMA consumes (k = l>>5 selects unit s vs s+4), so layer 0 -> layer 1 -> next time step needs no data movement.
+//  * Per-lane <-> unit-split conversion is one v_permlane32_swap per register pair, at kernel entry / exit only.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+enum { LW_B0 = 0, LW_X = 1, LW_H0 = 2, LW_B1 = 6, LW_I1 = 7, LW_H1 = 11, LW_LIN = 15, LW_LB = 19, LW_OUT = 20, LW_ROWS = 21 };
+struct LstmLane { float a[15]; float lw[4]; float lb, out_scale; };      // this lane's slice of the net
+LG_DEV LstmLane lstm_load(const float *table /* [LW_ROWS][64] */, int lane) {
+    LstmLane W;
+#pragma unroll
+    for (int i = 0; i < 15; i++) W.a[i] = table[i * 64 + lane];
+#pragma unroll
+    for (int i = 0; i < 4; i++) W.lw[i] = table[(LW_LIN + i) * 64 + lane];
+    W.lb = table[LW_LB * 64 + lane]; W.out_scale = table[LW_OUT * 64 + lane];
+    return W;
+}
+LG_DEV void swap32(float &a, float &b) {        // a <- [a.lo | b.lo], b <- [a.hi | b.hi]
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
+}
 LG_DEV float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.442695041f * x)); }
 LG_DEV float fast_tanh(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.885390082f * x)) - 1.0f; }
 
-struct LstmState { float h0[8], c0[8], h1[8], c1[8]; };
+// per-lane 8-vector (u[0..7] of this lane's row) -> unit-split pair (g0[s], g1[s]); the same call inverts it
+LG_DEV void lstm_split(const float (&u)[8], float (&g0)[4], float (&g1)[4]) {
+#pragma unroll
+    for (int s = 0; s < 4; s++) { g0[s] = u[s]; g1[s] = u[s + 4]; swap32(g0[s], g1[s]); }
+}
+LG_DEV void lstm_unsplit(const float (&g0)[4], const float (&g1)[4], float (&u)[8]) {
+#pragma unroll
+    for (int s = 0; s < 4; s++) { u[s] = g0[s]; u[s + 4] = g1[s]; swap32(u[s], u[s + 4]); }
+}
+struct LstmSplit { float h0[2][4], c0[2][4], h1[2][4], c1[2][4]; };      // [group][s]
 
-LG_DEV float actuator_row(cfp W, float pos_err, float vel, LstmState &s) {
-    cfp Wih0 = W + 3, Whh0 = Wih0 + 64, bih0 = Whh0 + 256, bhh0 = bih0 + 32;
-    cfp Wih1 = bhh0 + 32, Whh1 = Wih1 + 256, bih1 = Whh1 + 256, bhh1 = bih1 + 32;
-    cfp lw = bhh1 + 32, lb = lw + 8;
-    float x0 = pos_err * W[0], x1 = vel * W[1];
-    float g[32];
+LG_DEV void lstm_cell(const f32x16 &g, float (&h)[4], float (&c)[4]) {
 #pragma unroll
-    for (int r = 0; r < 32; r++) {
-        float a = Wih0[2 * r] * x0 + Wih0[2 * r + 1] * x1 + bih0[r];
-        float b = bhh0[r];
-#pragma unroll
-        for (int k = 0; k < 8; k++) b += Whh0[8 * r + k] * s.h0[k];
-        g[r] = a + b;
+    for (int u = 0; u < 4; u++) {
+        float cn = fast_sigmoid(g[4 + u]) * c[u] + fast_sigmoid(g[u]) * fast_tanh(g[8 + u]);
+        c[u] = cn; h[u] = fast_sigmoid(g[12 + u]) * fast_tanh(cn);
     }
+}
+// One time step for the wave's 64 rows.  (pos_err, vel) are this lane's row; returns this lane's torque.
+// Must be executed with all 64 lanes active.
+LG_DEV float actuator_step_mfma(const LstmLane &W, float pos_err, float vel, LstmSplit &st) {
+    float xg0 = pos_err, xg1 = vel;               // in_scale is folded into the A operand (exact: 2 and 0.25)
+    swap32(xg0, xg1);                             // xg0 = B operand of group 0, xg1 of group 1
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    float part[2];
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
-        float c = fast_sigmoid(g[8 + u]) * s.c0[u] + fast_sigmoid(g[u]) * fast_tanh(g[16 + u]);
-        s.c0[u] = c; s.h0[u] = fast_sigmoid(g[24 + u]) * fast_tanh(c);
+    for (int g = 0; g < 2; g++) {
+        f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(W.a[LW_B0], 1.0f, zero, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(W.a[LW_X], g ? xg1 : xg0, acc, 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < 4; s++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(W.a[LW_H0 + s], st.h0[g][s], acc, 0, 0, 0);
+        lstm_cell(acc, st.h0[g], st.c0[g]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(W.a[LW_B1], 1.0f, zero, 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < 4; s++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(W.a[LW_I1 + s], st.h0[g][s], acc, 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < 4; s++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(W.a[LW_H1 + s], st.h1[g][s], acc, 0, 0, 0);
+        lstm_cell(acc, st.h1[g], st.c1[g]);
+        float p = 0.0f;
+#pragma unroll
+        for (int u = 0; u < 4; u++) p += W.lw[u] * st.h1[g][u];
+        part[g] = p;
     }
-#pragma unroll
-    for (int r = 0; r < 32; r++) {
-        float a = bih1[r], b = bhh1[r];
-#pragma unroll
-        for (int k = 0; k < 8; k++) { a += Wih1[8 * r + k] * s.h0[k]; b += Whh1[8 * r + k] * s.h1[k]; }
-        g[r] = a + b;
-    }
-    float y = lb[0];
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-        float c = fast_sigmoid(g[8 + u]) * s.c1[u] + fast_sigmoid(g[u]) * fast_tanh(g[16 + u]);
-        s.c1[u] = c; s.h1[u] = fast_sigmoid(g[24 + u]) * fast_tanh(c);
-        y += lw[u] * s.h1[u];
-    }
-    return W[2] * y;
+    swap32(part[0], part[1]);                     // lanes < 32: (units 0-3, units 4-7) of group 0's row; lanes >= 32: group 1's
+    return W.out_scale * ((part[0] + part[1]) + W.lb);
 }
 
 }  // namespace lg

@@ -48,7 +48,7 @@ struct KArgs {                 // passed by value: lives in the kernarg segment 
     lg_buffers B;
     BaseTab    base;
     const float *limb_table;   // [K][STRIDE] device
-    const float *weights;      // [972] device or null
+    const float *weights;      // [LW_ROWS][64] per-lane MFMA operand table of the actuator net, or null
     const float *actions_in;   // [N, ndof]
     const int32_t *env_ids;    // reset kernel only
     int32_t    count;
@@ -398,7 +398,7 @@ LG_DEV void reset_values(const KArgs &A, const float *tab, int e, int k, int64_t
 // ------------------------------------------------------------------ observations (legged_robot.py:212-230, :100-101)
 // lane k owns slots k*L..k*L+L-1 of each of the four 12-wide groups [base|dof_pos|dof_vel|actions]
 template <class T>
-LG_DEV void write_observations(const KArgs &A, int e, int k, bool live, const float *root, const float (&q)[T::L],
+LG_DEV void write_observations(const KArgs &A, int e, int k, bool live, int64_t step, const float *root, const float (&q)[T::L],
                                const float (&qd)[T::L], const float (&act)[T::L], const float *tab, V3 blv, V3 bav, V3 pg,
                                const float (&cmd)[4]) {
     constexpr int K = T::K, L = T::L;
@@ -425,8 +425,8 @@ LG_DEV void write_observations(const KArgs &A, int e, int k, bool live, const fl
     for (int g = 0; g < 4; g++) {
         float u[4], u2[4];
         if (P.add_noise) {
-            rand4(P.seed, e, A.step, RNG_NOISE, (g * K + k) * 2, u);
-            if (L > 4) rand4(P.seed, e, A.step, RNG_NOISE, (g * K + k) * 2 + 1, u2);
+            rand4(P.seed, e, step, RNG_NOISE, (g * K + k) * 2, u);
+            if (L > 4) rand4(P.seed, e, step, RNG_NOISE, (g * K + k) * 2 + 1, u2);
         }
 #pragma unroll
         for (int j = 0; j < L; j++) {
@@ -444,7 +444,7 @@ LG_DEV void write_observations(const KArgs &A, int e, int k, bool live, const fl
         const int nchunk = (P.num_height_points + 3) >> 2;
         for (int c = k; c < nchunk; c += K) {          // chunk c = points 4c..4c+3, one Philox block each
             float u[4] = {0, 0, 0, 0};
-            if (P.add_noise) rand4(P.seed, e, A.step, RNG_NOISE_H, c, u);
+            if (P.add_noise) rand4(P.seed, e, step, RNG_NOISE_H, c, u);
 #pragma unroll
             for (int t = 0; t < 4; t++) {
                 int i = 4 * c + t;
@@ -484,6 +484,7 @@ __global__ void __launch_bounds__(LG_BLOCK) k_step(const KArgs A) {
     if (!live) e = N - 1;
     const float *tab = lds_tab + k * Tab<T>::STRIDE;
     const int d0 = e * ND + k * L;                                // first dof of this lane
+    const int64_t step = A.step >= 0 ? A.step : B.step_counter[0] + 1;   // -1: self-advancing (HIP-graph replay)
 
     // ---- load persistent state (read once per env-step)
     float root[13], q[L], qd[L], act[L], tau[L];
@@ -498,17 +499,22 @@ __global__ void __launch_bounds__(LG_BLOCK) k_step(const KArgs A) {
         tau[j] = 0.0f;
     }
     const size_t plane = (size_t)N * ND;
+    LstmLane LW;
     if (NET) {
+        LW = lstm_load(A.weights, threadIdx.x & 63);
+        // actuator state: global (per-row 8-vectors) -> unit-split MFMA layout, parked in LDS between uses
 #pragma unroll
         for (int j = 0; j < L; j++) {
-            const float4 *h0 = reinterpret_cast<const float4 *>(B.sea_hidden_state + (size_t)(d0 + j) * 8);
-            const float4 *c0 = reinterpret_cast<const float4 *>(B.sea_cell_state + (size_t)(d0 + j) * 8);
-            const float4 *h1 = reinterpret_cast<const float4 *>(B.sea_hidden_state + (plane + d0 + j) * 8);
-            const float4 *c1 = reinterpret_cast<const float4 *>(B.sea_cell_state + (plane + d0 + j) * 8);
-            lds_lstm[j * 8 + 0][threadIdx.x] = h0[0]; lds_lstm[j * 8 + 1][threadIdx.x] = h0[1];
-            lds_lstm[j * 8 + 2][threadIdx.x] = c0[0]; lds_lstm[j * 8 + 3][threadIdx.x] = c0[1];
-            lds_lstm[j * 8 + 4][threadIdx.x] = h1[0]; lds_lstm[j * 8 + 5][threadIdx.x] = h1[1];
-            lds_lstm[j * 8 + 6][threadIdx.x] = c1[0]; lds_lstm[j * 8 + 7][threadIdx.x] = c1[1];
+            const float *src[4] = {B.sea_hidden_state + (size_t)(d0 + j) * 8, B.sea_cell_state + (size_t)(d0 + j) * 8,
+                                   B.sea_hidden_state + (plane + d0 + j) * 8, B.sea_cell_state + (plane + d0 + j) * 8};
+#pragma unroll
+            for (int a = 0; a < 4; a++) {
+                float4 lo = reinterpret_cast<const float4 *>(src[a])[0], hi = reinterpret_cast<const float4 *>(src[a])[1];
+                float u[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}, g0[4], g1[4];
+                lstm_split(u, g0, g1);
+                lds_lstm[j * 8 + 2 * a][threadIdx.x] = make_float4(g0[0], g0[1], g0[2], g0[3]);
+                lds_lstm[j * 8 + 2 * a + 1][threadIdx.x] = make_float4(g1[0], g1[1], g1[2], g1[3]);
+            }
         }
     }
     const float mu = 0.5f * ((B.friction_coeffs ? B.friction_coeffs[e] : 1.0f) + P.ground_friction);
@@ -531,22 +537,21 @@ __global__ void __launch_bounds__(LG_BLOCK) k_step(const KArgs A) {
 #pragma unroll 1
     for (int it = 0; it < P.decimation; it++) {
         if (NET) {
-            cfp W = (cfp)(uintptr_t)A.weights;
 #pragma unroll 1
             for (int j = 0; j < L; j++) {
-                LstmState s;
+                LstmSplit st;
                 float4 t;
 #define LD(dst, slot) t = lds_lstm[j * 8 + slot][threadIdx.x]; dst[0] = t.x; dst[1] = t.y; dst[2] = t.z; dst[3] = t.w;
-                LD(s.h0, 0) LD((s.h0 + 4), 1) LD(s.c0, 2) LD((s.c0 + 4), 3) LD(s.h1, 4) LD((s.h1 + 4), 5) LD(s.c1, 6) LD((s.c1 + 4), 7)
+                LD(st.h0[0], 0) LD(st.h0[1], 1) LD(st.c0[0], 2) LD(st.c0[1], 3) LD(st.h1[0], 4) LD(st.h1[1], 5) LD(st.c1[0], 6) LD(st.c1[1], 7)
 #undef LD
                 float qj = 0, qdj = 0, aj = 0, q0j = tab[j * LG_JS + J_Q0];
 #pragma unroll
                 for (int jj = 0; jj < L; jj++) if (jj == j) { qj = q[jj]; qdj = qd[jj]; aj = act[jj]; }
-                float t_out = actuator_row(W, aj * P.action_scale + q0j - qj, qdj, s);
+                float t_out = actuator_step_mfma(LW, aj * P.action_scale + q0j - qj, qdj, st);
 #pragma unroll
                 for (int jj = 0; jj < L; jj++) if (jj == j) tau[jj] = t_out;
 #define ST(src, slot) lds_lstm[j * 8 + slot][threadIdx.x] = make_float4(src[0], src[1], src[2], src[3]);
-                ST(s.h0, 0) ST((s.h0 + 4), 1) ST(s.c0, 2) ST((s.c0 + 4), 3) ST(s.h1, 4) ST((s.h1 + 4), 5) ST(s.c1, 6) ST((s.c1 + 4), 7)
+                ST(st.h0[0], 0) ST(st.h0[1], 1) ST(st.c0[0], 2) ST(st.c0[1], 3) ST(st.h1[0], 4) ST(st.h1[1], 5) ST(st.c1[0], 6) ST(st.c1[1], 7)
 #undef ST
             }
         } else {
@@ -564,7 +569,7 @@ __global__ void __launch_bounds__(LG_BLOCK) k_step(const KArgs A) {
 #pragma unroll
     for (int i = 0; i < 4; i++) cmd[i] = B.commands[(size_t)e * 4 + i];
     // _post_physics_step_callback :329-345
-    if (ep_len % P.resample_interval == 0) resample_commands(P, e, A.step, RNG_CMD_STEP, cmd);
+    if (ep_len % P.resample_interval == 0) resample_commands(P, e, step, RNG_CMD_STEP, cmd);
     if (P.heading_command) {
         V3 fwd = quat_apply(root + 3, v3(1, 0, 0));
         float heading = atan2f(fwd.y, fwd.x);
@@ -590,9 +595,9 @@ __global__ void __launch_bounds__(LG_BLOCK) k_step(const KArgs A) {
                 }
             }
     }
-    if (P.push_interval > 0 && A.step % P.push_interval == 0) {                     // _push_robots :438-444
+    if (P.push_interval > 0 && step % P.push_interval == 0) {                     // _push_robots :438-444
         float u[4];
-        rand4(P.seed, e, A.step, RNG_PUSH, 0, u);
+        rand4(P.seed, e, step, RNG_PUSH, 0, u);
         root[7] = urange(-P.max_push_vel, P.max_push_vel, u[0]);
         root[8] = urange(-P.max_push_vel, P.max_push_vel, u[1]);
     }
@@ -718,22 +723,39 @@ __global__ void __launch_bounds__(LG_BLOCK) k_step(const KArgs A) {
     float origin[3] = {B.env_origins[(size_t)e * 3], B.env_origins[(size_t)e * 3 + 1], B.env_origins[(size_t)e * 3 + 2]};
     if (reset) {
         int level = 0; bool level_changed = false;
-        reset_values<T>(A, tab, e, k, A.step, root, q, qd, cmd, origin, level, level_changed);
+        reset_values<T>(A, tab, e, k, step, root, q, qd, cmd, origin, level, level_changed);
         if (writer && level_changed) {
             B.terrain_levels[e] = level;
             B.env_origins[(size_t)e * 3] = origin[0]; B.env_origins[(size_t)e * 3 + 1] = origin[1]; B.env_origins[(size_t)e * 3 + 2] = origin[2];
         }
-        fat = 0.0f; ep_len = 0;
-        if (NET) {
-#pragma unroll
-            for (int s = 0; s < L * 8; s++) lds_lstm[s][threadIdx.x] = make_float4(0, 0, 0, 0);
-        }
+        fat = 0.0f; ep_len = 0;     // the actuator state of reset envs is zeroed at write-back (anymal.py:59-60)
     }
 
     // compute_observations :130 (stale base-frame quantities for reset envs, as in the reference)
-    write_observations<T>(A, e, k, live, root, q, qd, act, tab, blv, bav, pg, cmd);
+    write_observations<T>(A, e, k, live, step, root, q, qd, act, tab, blv, bav, pg, cmd);
 
     // ---- write persistent state back (written once per env-step)
+    if (NET) {      // unit-split -> per-row 8-vectors (needs every lane of the wave), zeroed for reset envs
+#pragma unroll
+        for (int j = 0; j < L; j++) {
+            float *dst[4] = {B.sea_hidden_state + (size_t)(d0 + j) * 8, B.sea_cell_state + (size_t)(d0 + j) * 8,
+                             B.sea_hidden_state + (plane + d0 + j) * 8, B.sea_cell_state + (plane + d0 + j) * 8};
+#pragma unroll
+            for (int a = 0; a < 4; a++) {
+                float4 t0 = lds_lstm[j * 8 + 2 * a][threadIdx.x], t1 = lds_lstm[j * 8 + 2 * a + 1][threadIdx.x];
+                float g0[4] = {t0.x, t0.y, t0.z, t0.w}, g1[4] = {t1.x, t1.y, t1.z, t1.w}, u[8];
+                lstm_unsplit(g0, g1, u);
+                if (reset) {
+#pragma unroll
+                    for (int i = 0; i < 8; i++) u[i] = 0.0f;
+                }
+                if (live) {
+                    reinterpret_cast<float4 *>(dst[a])[0] = make_float4(u[0], u[1], u[2], u[3]);
+                    reinterpret_cast<float4 *>(dst[a])[1] = make_float4(u[4], u[5], u[6], u[7]);
+                }
+            }
+        }
+    }
     if (live) {
 #pragma unroll
         for (int j = 0; j < L; j++) {
@@ -745,19 +767,6 @@ __global__ void __launch_bounds__(LG_BLOCK) k_step(const KArgs A) {
         }
         B.feet_air_time[(size_t)e * K + k] = fat;
         B.last_contacts[(size_t)e * K + k] = lc;
-        if (NET) {
-#pragma unroll
-            for (int j = 0; j < L; j++) {
-                float4 *h0 = reinterpret_cast<float4 *>(B.sea_hidden_state + (size_t)(d0 + j) * 8);
-                float4 *c0 = reinterpret_cast<float4 *>(B.sea_cell_state + (size_t)(d0 + j) * 8);
-                float4 *h1 = reinterpret_cast<float4 *>(B.sea_hidden_state + (plane + d0 + j) * 8);
-                float4 *c1 = reinterpret_cast<float4 *>(B.sea_cell_state + (plane + d0 + j) * 8);
-                h0[0] = lds_lstm[j * 8 + 0][threadIdx.x]; h0[1] = lds_lstm[j * 8 + 1][threadIdx.x];
-                c0[0] = lds_lstm[j * 8 + 2][threadIdx.x]; c0[1] = lds_lstm[j * 8 + 3][threadIdx.x];
-                h1[0] = lds_lstm[j * 8 + 4][threadIdx.x]; h1[1] = lds_lstm[j * 8 + 5][threadIdx.x];
-                c1[0] = lds_lstm[j * 8 + 6][threadIdx.x]; c1[1] = lds_lstm[j * 8 + 7][threadIdx.x];
-            }
-        }
         if (k == 0) {
 #pragma unroll
             for (int i = 0; i < 13; i++) B.root_states[(size_t)e * 13 + i] = root[i];
@@ -844,6 +853,8 @@ __global__ void __launch_bounds__(LG_BLOCK) k_reset(const KArgs A) {
 __global__ void __launch_bounds__(64) k_extras(const KArgs A) {
     const lg_params &P = A.P;
     const int R = P.num_reward_slots, t = threadIdx.x;
+    if (A.count < 0 && t == 0 && A.B.step_counter)      // behind k_step: publish the step value it used
+        A.B.step_counter[0] = A.step >= 0 ? A.step : A.B.step_counter[0] + 1;
     float cnt = A.B.extras_accum[R];
     float v = (t < R) ? A.B.extras_accum[t] : 0.0f;
     __syncthreads();
@@ -862,18 +873,34 @@ __global__ void __launch_bounds__(64) k_extras(const KArgs A) {
 }
 
 // ------------------------------------------------------------------ sub-path kernels (parity tests drive these)
-__global__ void __launch_bounds__(256) k_actuator(const float *weights, const float *pos_err, const float *vel, float *torques,
-                                                   float *hidden, float *cell, int rows) {
-    int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= rows) return;
-    cfp W = (cfp)(uintptr_t)weights;
-    LstmState s;
-    float *h0 = hidden + (size_t)r * 8, *c0 = cell + (size_t)r * 8, *h1 = hidden + ((size_t)rows + r) * 8, *c1 = cell + ((size_t)rows + r) * 8;
+__global__ void __launch_bounds__(64) k_actuator(const float *table, const float *pos_err, const float *vel, float *torques,
+                                                  float *hidden, float *cell, int rows) {
+    const int lane = threadIdx.x;
+    int r = blockIdx.x * 64 + lane;
+    const bool live = r < rows;
+    if (!live) r = rows - 1;                      // every lane takes part in the MFMAs / swaps
+    const LstmLane W = lstm_load(table, lane);
+    float *ptr[4] = {hidden + (size_t)r * 8, cell + (size_t)r * 8, hidden + ((size_t)rows + r) * 8, cell + ((size_t)rows + r) * 8};
+    LstmSplit st;
+    float (*arr[4])[4] = {st.h0, st.c0, st.h1, st.c1};
 #pragma unroll
-    for (int u = 0; u < 8; u++) { s.h0[u] = h0[u]; s.c0[u] = c0[u]; s.h1[u] = h1[u]; s.c1[u] = c1[u]; }
-    torques[r] = actuator_row(W, pos_err[r], vel[r], s);
+    for (int a = 0; a < 4; a++) {
+        float u[8];
 #pragma unroll
-    for (int u = 0; u < 8; u++) { h0[u] = s.h0[u]; c0[u] = s.c0[u]; h1[u] = s.h1[u]; c1[u] = s.c1[u]; }
+        for (int i = 0; i < 8; i++) u[i] = ptr[a][i];
+        lstm_split(u, arr[a][0], arr[a][1]);
+    }
+    float t = actuator_step_mfma(W, pos_err[r], vel[r], st);
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        float u[8];
+        lstm_unsplit(arr[a][0], arr[a][1], u);
+        if (live) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) ptr[a][i] = u[i];
+        }
+    }
+    if (live) torques[r] = t;
 }
 
 template <class T, bool HF>
@@ -937,7 +964,7 @@ __global__ void __launch_bounds__(LG_BLOCK) k_obs(const KArgs A) {
     V3 blv = v3(B.base_lin_vel[(size_t)e * 3], B.base_lin_vel[(size_t)e * 3 + 1], B.base_lin_vel[(size_t)e * 3 + 2]);
     V3 bav = v3(B.base_ang_vel[(size_t)e * 3], B.base_ang_vel[(size_t)e * 3 + 1], B.base_ang_vel[(size_t)e * 3 + 2]);
     V3 pg = v3(B.projected_gravity[(size_t)e * 3], B.projected_gravity[(size_t)e * 3 + 1], B.projected_gravity[(size_t)e * 3 + 2]);
-    write_observations<T>(A, e, k, live, root, q, qd, act, tab, blv, bav, pg, cmd);
+    write_observations<T>(A, e, k, live, A.step, root, q, qd, act, tab, blv, bav, pg, cmd);
 }
 
 // ====================================================================  host side: C-ABI  ====================================================================
@@ -995,6 +1022,27 @@ template <class T> static void fill_limb_table(const lg_params &P, const lg_robo
     }
 }
 
+// Per-lane MFMA operand table of the actuator net (layout: lg_device.h "ANYdrive actuator net").
+// `w` is the 972-float blob: in_scale[2], out_scale, Wih0[32][2], Whh0[32][8], bih0, bhh0, Wih1[32][8], Whh1[32][8], bih1, bhh1, lw[8], lb.
+static void build_lstm_table(const float *w, float *t /* [LW_ROWS][64] */) {
+    const float *in_scale = w, *out_scale = w + 2, *Wih0 = w + 3, *Whh0 = Wih0 + 64, *bih0 = Whh0 + 256, *bhh0 = bih0 + 32;
+    const float *Wih1 = bhh0 + 32, *Whh1 = Wih1 + 256, *bih1 = Whh1 + 256, *bhh1 = bih1 + 32, *lw = bhh1 + 32, *lb = lw + 8;
+    for (int l = 0; l < 64; l++) {
+        const int g = l & 31, hb = l >> 5;
+        t[LW_B0 * 64 + l] = hb ? 0.0f : bih0[g] + bhh0[g];
+        t[LW_X * 64 + l] = Wih0[2 * g + hb] * in_scale[hb];
+        t[LW_B1 * 64 + l] = hb ? 0.0f : bih1[g] + bhh1[g];
+        for (int s = 0; s < 4; s++) {
+            t[(LW_H0 + s) * 64 + l] = Whh0[8 * g + s + 4 * hb];
+            t[(LW_I1 + s) * 64 + l] = Wih1[8 * g + s + 4 * hb];
+            t[(LW_H1 + s) * 64 + l] = Whh1[8 * g + s + 4 * hb];
+            t[(LW_LIN + s) * 64 + l] = lw[s + 4 * hb];
+        }
+        t[LW_LB * 64 + l] = lb[0];
+        t[LW_OUT * 64 + l] = out_scale[0];
+    }
+}
+
 static int upload_tables(lg_sim *s) {
     float host[LG_MAX_LIMBS * (LG_MAX_CHAIN * LG_JS + 4 * LG_MAX_LIMB_POINTS + 1)];
     size_t n;
@@ -1043,8 +1091,10 @@ int lg_create(const lg_params *params, const lg_robot_model *model, const float 
     memset(&s->B, 0, sizeof s->B);
     if (hipMalloc(&s->d_limb_table, sizeof(float) * LG_MAX_LIMBS * (LG_MAX_CHAIN * LG_JS + 4 * LG_MAX_LIMB_POINTS + 1)) != hipSuccess) { delete s; return fail(-10, "hipMalloc failed"); }
     if (s->has_net) {
-        if (hipMalloc(&s->d_weights, sizeof(float) * LG_ACTUATOR_FLOATS) != hipSuccess) { (void)hipFree(s->d_limb_table); delete s; return fail(-10, "hipMalloc failed"); }
-        if (hipMemcpy(s->d_weights, actuator_weights, sizeof(float) * LG_ACTUATOR_FLOATS, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(s->d_weights); (void)hipFree(s->d_limb_table); delete s; return fail(-10, "hipMemcpy failed"); }
+        float table[LW_ROWS * 64];
+        build_lstm_table(actuator_weights, table);
+        if (hipMalloc(&s->d_weights, sizeof table) != hipSuccess) { (void)hipFree(s->d_limb_table); delete s; return fail(-10, "hipMalloc failed"); }
+        if (hipMemcpy(s->d_weights, table, sizeof table, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(s->d_weights); (void)hipFree(s->d_limb_table); delete s; return fail(-10, "hipMemcpy failed"); }
     }
     int rc = upload_tables(s);
     if (rc) { lg_destroy(s); return rc; }
@@ -1084,6 +1134,7 @@ int lg_set_params(lg_sim *s, const lg_params *p) {
 int lg_step(lg_sim *s, const float *actions, int64_t common_step_counter, void *stream) {
     if (!s || !s->bound) return fail(-8, "lg_bind has not been called");
     if (!actions) return fail(-1, "null actions");
+    if (common_step_counter < 0 && !s->B.step_counter) return fail(-9, "common_step_counter = -1 needs a step_counter buffer");
     KArgs a; fill_args(s, a, common_step_counter); a.actions_in = actions;
     hipStream_t st = (hipStream_t)stream;
     const bool hf = s->P.terrain_type == LG_TERRAIN_HEIGHTFIELD;
@@ -1099,6 +1150,7 @@ int lg_step(lg_sim *s, const float *actions, int64_t common_step_counter, void *
         if (!hf) hipLaunchKernelGGL((k_step<CassieTraits, false, false>), g, b, 0, st, a);
         else hipLaunchKernelGGL((k_step<CassieTraits, false, true>), g, b, 0, st, a);
     }
+    a.count = -1;
     hipLaunchKernelGGL(k_extras, dim3(1), dim3(64), 0, st, a);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -1127,7 +1179,7 @@ int lg_reset_idx(lg_sim *s, const int32_t *env_ids, int32_t count, int64_t commo
 int lg_actuator_forward(lg_sim *s, const float *pos_err, const float *vel, float *torques, float *hidden, float *cell, int32_t rows, void *stream) {
     if (!s || !s->has_net) return fail(-2, "no actuator weights");
     if (rows <= 0) return 0;
-    hipLaunchKernelGGL(k_actuator, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, s->d_weights, pos_err, vel, torques, hidden, cell, rows);
+    hipLaunchKernelGGL(k_actuator, dim3((rows + 63) / 64), dim3(64), 0, (hipStream_t)stream, s->d_weights, pos_err, vel, torques, hidden, cell, rows);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -55,6 +55,31 @@ class LeggedRobot(BaseTask):
     def post_physics_step(self):
         raise RuntimeError("post_physics_step is fused into lg_step; call step()")
 
+    def make_graphed_step(self, policy_act, warmup=3):
+        """Capture ``actions = policy_act(obs_buf); step(actions)`` into one HIP graph and return a
+        zero-argument callable that replays it (launch-bound inner loop -> one hipGraphLaunch).
+        The step counter lives on the device while replaying (``lg_step(..., -1)``), the host copy is
+        advanced alongside.  ``policy_act`` must be capturable (no host syncs) and read ``self.obs_buf``."""
+        sim = self._sim
+        sim.buf["step_counter"].fill_(self.common_step_counter)
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                sim.step(policy_act(self.obs_buf), -1)
+                self.common_step_counter += 1
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            sim.step(policy_act(self.obs_buf), -1)
+        self._step_graph = graph
+
+        def replay():
+            graph.replay()
+            self.common_step_counter += 1
+            return self.obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf, self.extras
+        return replay
+
     def reset_idx(self, env_ids):
         """Reset the listed envs (reference :147-191) through ``lg_reset_idx``."""
         if len(env_ids) == 0:

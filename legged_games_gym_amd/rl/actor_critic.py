@@ -28,7 +28,7 @@ class ActorCritic(nn.Module):
         self.critic = _mlp(num_critic_obs, list(critic_hidden_dims), 1, activation)
         self.std = nn.Parameter(init_noise_std * torch.ones(num_actions))
         self.distribution = None
-        Normal.set_default_validate_args = False
+        Normal.set_default_validate_args(False)     # no host-syncing argument checks (also keeps act() graph-capturable)
 
     def reset(self, dones=None):
         pass
@@ -51,7 +51,10 @@ class ActorCritic(nn.Module):
 
     def act(self, observations, **kwargs):
         self.update_distribution(observations)
-        return self.distribution.sample()
+        # == self.distribution.sample(), written without torch.normal(tensor, tensor), whose std >= 0 check
+        # synchronises with the host (and therefore cannot be captured into a HIP graph)
+        mean = self.distribution.mean
+        return mean + self.distribution.stddev * torch.randn_like(mean)
 
     def get_actions_log_prob(self, actions):
         return self.distribution.log_prob(actions).sum(dim=-1)

@@ -164,7 +164,7 @@ def buffer_spec(p, model) -> Dict[str, Tuple[Tuple[int, ...], str]]:
         "last_dof_vel": ((N, n), "float32"), "last_root_vel": ((N, 6), "float32"), "commands": ((N, 4), "float32"),
         "feet_air_time": ((N, K), "float32"), "last_contacts": ((N, K), "bool"),
         "base_lin_vel": ((N, 3), "float32"), "base_ang_vel": ((N, 3), "float32"), "projected_gravity": ((N, 3), "float32"),
-        "episode_sums": ((R, N), "float32"), "episode_means": ((R + 1,), "float32"), "extras_accum": ((R + 1,), "float32"),
+        "episode_sums": ((R, N), "float32"), "episode_means": ((R + 1,), "float32"), "extras_accum": ((R + 1,), "float32"), "step_counter": ((1,), "int64"),
         "env_origins": ((N, 3), "float32"), "friction_coeffs": ((N,), "float32"), "base_mass_delta": ((N,), "float32"),
     }
     if p.measure_heights:

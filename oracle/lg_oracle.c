@@ -854,6 +854,8 @@ int lgo_set_threads(lgo_sim *s, int n) { s->threads = n < 1 ? 1 : n; return 0; }
 
 int lgo_step(lgo_sim *s, const float *actions, int64_t step, void *stream) {
     (void)stream;
+    if (step < 0) step = s->B.step_counter[0] + 1;
+    if (s->B.step_counter) s->B.step_counter[0] = step;
     const int nd = s->R.num_limbs * s->R.chain_len;
 #pragma omp parallel for schedule(static) num_threads(s->threads)
     for (int e = 0; e < s->P.num_envs; e++) {

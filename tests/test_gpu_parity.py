@@ -155,7 +155,8 @@ def test_physics_substep_parity(task):
     assert np.abs(q_o[..., 0] - q_d[..., 0]).max() < 2e-5               # dof_pos [rad]
     r_o, r_d = o.buf["root_states"], get(d, "root_states")
     dv = np.abs(r_o[:, 7:13] - v0).max(axis=1)
-    assert (np.abs(r_o - r_d).max(axis=1) <= 1e-4 * (1.0 + dv)).all()
+    fmax = np.abs(o.buf["contact_forces"]).max(axis=(1, 2))
+    assert (np.abs(r_o - r_d).max(axis=1) <= 3e-4 * (1.0 + dv) + 1e-7 * fmax).all()
     cf_o, cf_d = o.buf["contact_forces"], get(d, "contact_forces")
     assert (np.abs(cf_o).sum(axis=(1, 2)) > 1).sum() > N // 10            # contacts did occur
     assert np.abs(cf_o - cf_d).max() < 2e-4 * max(1.0, np.abs(cf_o).max()) + 0.5
