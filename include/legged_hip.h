@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LG_ABI_VERSION        5
+#define LG_ABI_VERSION        6
 
 #define LG_MAX_LIMBS          4
 #define LG_MAX_CHAIN          6
@@ -86,7 +86,7 @@ typedef struct lg_params {
     float   sim_dt, gravity[3];
     /* contact + joint-limit model of the built-in rigid-body engine */
     float   contact_stiffness, contact_damping, friction_damping, contact_margin;
-    float   ground_friction, limit_stiffness, limit_damping, _padf0;
+    float   ground_friction, limit_stiffness, limit_damping, stick_velocity; /* Coulomb regularisation speed [m/s] */
     /* control: legged_robot.py:371-395, anymal.py:71-81 */
     float   action_scale, clip_actions, clip_observations, _padf1;
     float   p_gains[LG_MAX_DOF], d_gains[LG_MAX_DOF], default_dof_pos[LG_MAX_DOF], torque_limits[LG_MAX_DOF];

@@ -16,7 +16,7 @@ from typing import Dict, Optional
 
 import numpy as np
 
-LG_ABI_VERSION = 5
+LG_ABI_VERSION = 6
 LG_MAX_LIMBS, LG_MAX_CHAIN, LG_MAX_DOF = 4, 6, 12
 LG_MAX_LIMB_POINTS, LG_MAX_BASE_POINTS, LG_MAX_BODIES = 8, 4, 20
 LG_MAX_HEIGHT_POINTS, LG_ACTUATOR_FLOATS = 192, 972
@@ -57,7 +57,7 @@ class lg_params(C.Structure):
         ("abi_version", i32), ("num_envs", i32), ("decimation", i32), ("control_type", i32),
         ("sim_dt", f32), ("gravity", f32 * 3),
         ("contact_stiffness", f32), ("contact_damping", f32), ("friction_damping", f32), ("contact_margin", f32),
-        ("ground_friction", f32), ("limit_stiffness", f32), ("limit_damping", f32), ("_padf0", f32),
+        ("ground_friction", f32), ("limit_stiffness", f32), ("limit_damping", f32), ("stick_velocity", f32),
         ("action_scale", f32), ("clip_actions", f32), ("clip_observations", f32), ("_padf1", f32),
         ("p_gains", f32 * LG_MAX_DOF), ("d_gains", f32 * LG_MAX_DOF), ("default_dof_pos", f32 * LG_MAX_DOF),
         ("torque_limits", f32 * LG_MAX_DOF),

@@ -79,11 +79,16 @@ template <bool HF> LG_DEV void ground_query(const KArgs &A, float x, float y, fl
 }
 
 // ------------------------------------------------------------------ one 5 ms rigid-body step for (env, limb)
-struct Contact { V3 r, n, vc, f; float depth, bt; bool on; };
+struct Contact { V3 r, n, vc, f; float depth, bt, vtn; bool on; };
 
-LG_DEV void contact_setup(Contact &c, const lg_params &P, V3 r, V3 n, float depth, V3 vc) {
-    c.r = r; c.n = n; c.depth = depth; c.vc = vc; c.on = depth > -P.contact_margin;
-    c.bt = P.friction_damping; c.f = v3(0, 0, 0);
+// fprev = previous sub-step's net contact force on the point's report body (seeds the friction secant)
+LG_DEV void contact_setup(Contact &c, const lg_params &P, float mu, V3 r, V3 n, float depth, V3 vc, V3 fprev) {
+    c.r = r; c.n = n; c.depth = depth; c.vc = vc; c.on = depth > -P.contact_margin; c.f = v3(0, 0, 0);
+    float vn0 = dot(n, vc);
+    V3 vt0 = vc - n * vn0;
+    c.vtn = sqrtf(dot(vt0, vt0));
+    float fn_est = fmaxf(dot(n, fprev), 0.0f);
+    c.bt = fminf(P.friction_damping, mu * fn_est / fmaxf(c.vtn, P.stick_velocity));
 }
 LG_DEV void contact_assemble(const Contact &c, const lg_params &P, float kn, AI &IA, S6 &pA) {
     if (c.on) {
@@ -105,10 +110,8 @@ LG_DEV void contact_evaluate(Contact &c, const lg_params &P, float kn, float mu,
         float fn = P.contact_stiffness * c.depth - kn * vn;
         if (fn <= 0.0f) { c.on = false; c.f = v3(0, 0, 0); }
         else {
-            float vtn = sqrtf(dot(vt, vt)), ft = c.bt * vtn;
-            if (ft > mu * fn) { c.bt = mu * fn / fmaxf(vtn, 1e-9f); ft = mu * fn; }
-            V3 tdir = (vtn > 1e-12f) ? vt * (1.0f / vtn) : v3(0, 0, 0);
-            c.f = c.n * fn - tdir * ft;
+            c.f = c.n * fn - vt * c.bt;                                                      // force this pass applied
+            c.bt = fminf(P.friction_damping, mu * fn / fmaxf(c.vtn, P.stick_velocity));       // secant for the next pass
         }
     }
 }
@@ -167,7 +170,7 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, float (&root)[13],
             V3 r = mul(R0, v3(A.base.pts[i][0], A.base.pts[i][1], A.base.pts[i][2]));
             float h; V3 n;
             ground_query<HF>(A, root[0] + r.x, root[1] + r.y, h, n);
-            contact_setup(cb[i], P, r, n, A.base.pts[i][3] - (root[2] + r.z - h) * n.z, v0 + cross(w0, r));
+            contact_setup(cb[i], P, mu, r, n, A.base.pts[i][3] - (root[2] + r.z - h) * n.z, v0 + cross(w0, r), v3(Fbase[0], Fbase[1], Fbase[2]));
         }
     }
     {
@@ -207,7 +210,8 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, float (&root)[13],
                 V3 pw = rj + r;
                 float h; V3 n;
                 ground_query<HF>(A, root[0] + pw.x, root[1] + pw.y, h, n);
-                contact_setup(cl[i], P, r, n, tp[3] - (root[2] + pw.z - h) * n.z, vj + cross(wj, r));
+                contact_setup(cl[i], P, mu, r, n, tp[3] - (root[2] + pw.z - h) * n.z, vj + cross(wj, r),
+                              v3(Frep[T::pt_rep(i)][0], Frep[T::pt_rep(i)][1], Frep[T::pt_rep(i)][2]));
             }
             Rpar = Rj; rpar = rj; wpar = wj; vpar = vj;
         }
@@ -525,12 +529,14 @@ __global__ void __launch_bounds__(LG_BLOCK) k_step(const KArgs A) {
 
     // ---- decimation x (torque -> physics)   legged_robot.py:90-96
     float Frep[NREP][3], Fbase[3];
-    if (P.decimation == 0) {      // post-physics only (parity tests): contact forces / torques are inputs
+    {   // last step's net contact forces: inputs of the friction estimate (and of the post-physics-only test mode)
         const float *cf = B.contact_forces + ((size_t)e * (1 + K * NREP) + 1 + k * NREP) * 3;
 #pragma unroll
         for (int r = 0; r < NREP; r++) { Frep[r][0] = cf[3 * r]; Frep[r][1] = cf[3 * r + 1]; Frep[r][2] = cf[3 * r + 2]; }
         const float *c0 = B.contact_forces + (size_t)e * (1 + K * NREP) * 3;
         Fbase[0] = c0[0]; Fbase[1] = c0[1]; Fbase[2] = c0[2];
+    }
+    if (P.decimation == 0) {      // post-physics only (parity tests): torques are an input
 #pragma unroll
         for (int j = 0; j < L; j++) tau[j] = B.torques[d0 + j];
     }
@@ -924,6 +930,14 @@ __global__ void __launch_bounds__(LG_BLOCK) k_physics(const KArgs A, const float
     for (int j = 0; j < L; j++) { q[j] = B.dof_state[2 * (d0 + j)]; qd[j] = B.dof_state[2 * (d0 + j) + 1]; tau[j] = torques[d0 + j]; }
     const float mu = 0.5f * ((B.friction_coeffs ? B.friction_coeffs[e] : 1.0f) + A.P.ground_friction);
     const float base_mass = A.base.mass + (B.base_mass_delta ? B.base_mass_delta[e] : 0.0f);
+    {
+        const float *cf = B.contact_forces + ((size_t)e * (1 + K * NREP) + 1 + k * NREP) * 3;
+#pragma unroll
+        for (int r = 0; r < NREP; r++) { Frep[r][0] = cf[3 * r]; Frep[r][1] = cf[3 * r + 1]; Frep[r][2] = cf[3 * r + 2]; }
+        const float *c0 = B.contact_forces + (size_t)e * (1 + K * NREP) * 3;
+        Fbase[0] = c0[0]; Fbase[1] = c0[1]; Fbase[2] = c0[2];
+    }
+    write_contacts = 1;           // the net contact forces also seed the next sub-step's friction estimate
     physics_substep<T, HF>(A, tab, root, q, qd, tau, base_mass, mu, Frep, Fbase);
     if (!live) return;
 #pragma unroll

@@ -24,7 +24,8 @@ class EngineOptions:
     the reference config (PhysX hides them).  See DESIGN.md "Physics step"."""
     contact_stiffness: float = 1.0e6     # N/m, implicit
     contact_damping: float = 2.0e4       # N s/m normal damping (depenetration time constant b/k = 20 ms)
-    friction_damping: float = 2.5e4      # N s/m tangential stick impedance
+    friction_damping: float = 2.5e4      # N s/m tangential stick impedance (upper bound of the Coulomb secant)
+    stick_velocity: float = 1.0e-3       # m/s, regularisation speed of the Coulomb law
     limit_stiffness: float = 2.0e4       # N m/rad, implicit joint-limit spring
     limit_damping: float = 2.0e2         # N m s/rad
     armature: float = 0.0
@@ -70,6 +71,7 @@ def build_params(cfg, model, sim_dt: float, num_envs: int, seed: int, gravity=(0
     p.friction_damping, p.contact_margin = engine.friction_damping, contact_offset
     p.ground_friction = cfg.terrain.static_friction
     p.limit_stiffness, p.limit_damping = engine.limit_stiffness, engine.limit_damping
+    p.stick_velocity = engine.stick_velocity
     p.action_scale = cfg.control.action_scale
     p.clip_actions, p.clip_observations = cfg.normalization.clip_actions, cfg.normalization.clip_observations
 

@@ -18,8 +18,8 @@
  *      *defines* the rigid-body step the HIP kernels must reproduce:
  *      floating-base articulated-body algorithm in world-aligned coordinates
  *      about the base origin, implicit (backward-Euler) spring-damper contacts
- *      and joint limits folded into the articulated inertias, two-pass
- *      stick / slide / separate classification, semi-implicit Euler.
+ *      and joint limits folded into the articulated inertias, implicit regularised
+ *      Coulomb friction refined over two passes, semi-implicit Euler.
  *      See DESIGN.md "Physics step".
  *
  * Same C-ABI as include/legged_hip.h with prefix lgo_ and HOST pointers.
@@ -266,7 +266,7 @@ typedef struct {
     int   body;        /* dynamic body: 0 base, 1+dof */
     int   report;
     v3    r, n, vc;    /* r: rel. base origin (world axes); n: ground normal; vc: point velocity */
-    float depth, kn, bt, mu;
+    float depth, kn, bt, mu, vtn;   /* vtn = tangential speed at the start of the step */
     int   on;
     v3    f;           /* resulting force (world) */
 } contact_t;
@@ -383,8 +383,17 @@ static void physics_substep_env(const lgo_sim *s, int e, const float *tau, int w
             c->on = c->depth > -P->contact_margin;
             c->vc = add(vb[b], cross(wb[b], c->r));
             c->kn = P->contact_stiffness * dt + P->contact_damping;
-            c->bt = P->friction_damping;
             c->mu = mu_env;
+            {   /* implicit regularised Coulomb friction: tangential impedance = secant of mu f_n / |v_t| at the slip speed
+                 * the step starts with, capped by the stick impedance; f_n estimated from the previous sub-step's net
+                 * contact force on the point's report body (contact_forces is persistent state). */
+                float vn0 = dot(c->n, c->vc);
+                v3 vt0 = sub(c->vc, scl(c->n, vn0));
+                c->vtn = sqrtf(dot(vt0, vt0));
+                const float *fp = s->B.contact_forces + ((size_t)e * M->num_bodies + pt->report_body) * 3;
+                float fn_est = fmaxf(dot(c->n, V(fp[0], fp[1], fp[2])), 0.0f);
+                c->bt = fminf(P->friction_damping, c->mu * fn_est / fmaxf(c->vtn, P->stick_velocity));
+            }
             c->f = V(0, 0, 0);
             nc++;
         }
@@ -462,13 +471,8 @@ static void physics_substep_env(const lgo_sim *s, int e, const float *tau, int w
             v3 vt = sub(vn_, scl(c->n, vn));
             float fn = P->contact_stiffness * c->depth - c->kn * vn;
             if (fn <= 0.0f) { c->on = 0; c->f = V(0, 0, 0); continue; }
-            float vtn = sqrtf(dot(vt, vt)), ft = c->bt * vtn;
-            if (ft > c->mu * fn) {       /* sliding: secant viscosity that yields |f_t| = mu f_n at this slip speed */
-                c->bt = c->mu * fn / fmaxf(vtn, 1e-9f);
-                ft = c->mu * fn;
-            }
-            v3 tdir = (vtn > 1e-12f) ? scl(vt, 1.0f / vtn) : V(0, 0, 0);
-            c->f = sub(scl(c->n, fn), scl(tdir, ft));
+            c->f = sub(scl(c->n, fn), scl(vt, c->bt));                           /* force this pass applied */
+            c->bt = fminf(P->friction_damping, c->mu * fn / fmaxf(c->vtn, P->stick_velocity));   /* secant for the next pass */
         }
     }
 
@@ -492,7 +496,8 @@ static void physics_substep_env(const lgo_sim *s, int e, const float *tau, int w
         float inv = 1.0f / sqrtf(nx * nx + ny * ny + nz * nz + nw * nw);
         root[3] = nx * inv; root[4] = ny * inv; root[5] = nz * inv; root[6] = nw * inv;
     }
-    if (write_contacts) {
+    (void)write_contacts;       /* always: the net contact forces also seed the next sub-step's friction estimate */
+    {
         float *cf = s->B.contact_forces + (size_t)e * M->num_bodies * 3;
         for (int i = 0; i < M->num_bodies * 3; i++) cf[i] = 0.0f;
         for (int i = 0; i < nc; i++) { cf[3 * ct[i].report] += ct[i].f.x; cf[3 * ct[i].report + 1] += ct[i].f.y; cf[3 * ct[i].report + 2] += ct[i].f.z; }
