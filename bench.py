@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--num-envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--torch-policy", action="store_true", help="policy forward with torch ops instead of the fused MFMA actor kernel")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one captured HIP graph per step")
     ap.add_argument("--event-steps", type=int, default=200, help="eager steps timed with HIP events for the roofline object")
     a = ap.parse_args()
@@ -73,6 +74,12 @@ def main():
     policy = ActorCritic(env.num_obs, env.num_obs, env.num_actions, **pol).to(dev)
     with contextlib.redirect_stdout(io.StringIO()):
         obs, _ = env.reset()
+    if a.torch_policy:
+        policy_act = policy.act
+    else:
+        from legged_games_gym_amd.rl import FusedActor
+        fused = FusedActor(policy, dev, seed=train_cfg.seed + rank, step_counter=env._sim.buf["step_counter"])
+        policy_act = fused.act
 
     def sync():
         if world > 1:
@@ -82,9 +89,9 @@ def main():
     with torch.inference_mode():
         if a.no_graph:
             def one_step():
-                env.step(policy.act(env.obs_buf))             # the full VecEnv step (one lg_step call)
+                env.step(policy_act(env.obs_buf))             # the full VecEnv step (one lg_step call)
         else:
-            one_step = env.make_graphed_step(policy.act)      # policy forward + sampling + lg_step in ONE HIP graph
+            one_step = env.make_graphed_step(policy_act)      # policy forward + sampling + lg_step in ONE HIP graph
         for _ in range(a.warmup):
             one_step()
         sync()
@@ -98,7 +105,7 @@ def main():
         n_ev = max(1, min(a.event_steps, a.steps))
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
         for s_, e_ in ev:
-            actions = policy.act(env.obs_buf)
+            actions = policy_act(env.obs_buf)
             s_.record()
             env.step(actions)
             e_.record()
@@ -126,7 +133,8 @@ def main():
                                    "fixed command (0.5,0,0), obs noise + friction/mass randomisation + pushes on",
                        "envs_per_gpu": a.num_envs, "decimation": int(env.cfg.control.decimation), "sim_dt": float(env.sim_params.dt),
                        "parallelism": f"env-sharded x{world}", "state_finite": finite,
-                       "launch": "eager" if a.no_graph else "one captured HIP graph per policy step (torch policy ops + lg_step)"},
+                       "launch": "eager" if a.no_graph else "one captured HIP graph per policy step (policy + lg_step)",
+                       "policy": "torch ops (hipBLASLt)" if a.torch_policy else "fused MFMA actor kernel (lg_policy_act, v_mfma_f32_16x16x4_f32)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel": "k_step<AnymalTraits,NET,plane>" if a.task != "cassie" else "k_step<CassieTraits>",
                          "kernel_ms": kern_ms, "kernel_ms_method": f"HIP events around {n_ev} eager lg_step launches (k_step + k_extras) right after the timed region",

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LG_ABI_VERSION        6
+#define LG_ABI_VERSION        7
 
 #define LG_MAX_LIMBS          4
 #define LG_MAX_CHAIN          6
@@ -185,6 +185,19 @@ int  lg_compute_observations_only(lg_sim *sim, int64_t common_step_counter, void
 /* Update params that the Python surface may change between steps
  * (command ranges by the curriculum, legged_robot.py:471-483). */
 int  lg_set_params(lg_sim *sim, const lg_params *params);
+
+/* Fused rollout-time actor: actions = MLP(obs) + std * eps (rsl_rl ActorCritic.act, [EXTERNAL]; widths from
+ * legged_robot_config.py:204-209 / anymal_c_flat_config.py:62-65), ELU hidden activations, 3 hidden layers.
+ * `weights[i]`/`biases[i]` are HOST arrays in torch.nn.Linear layout ([out,in] row-major / [out]); they are repacked into
+ * the MFMA operand layout and copied to the device.  Supported widths: hidden multiples of 16, <= 512. */
+typedef struct lg_policy lg_policy;
+int  lg_policy_create(const int32_t dims[5] /* obs, h1, h2, h3, actions */, const float *const weights[4],
+                      const float *const biases[4], const float *std, int device_id, lg_policy **out);
+void lg_policy_destroy(lg_policy *p);
+/* obs [N,dims[0]] -> actions [N,dims[4]] (and mean if non-null), device pointers.  `step` selects the noise stream
+ * (>= 0) or, when -1, (*step_counter + 1) is read on the device (graph replay).  deterministic != 0 returns the mean. */
+int  lg_policy_act(lg_policy *p, const float *obs, float *actions, float *mean, int32_t num_envs, uint64_t seed,
+                   int64_t step, const int64_t *step_counter, int32_t deterministic, void *stream);
 
 const char *lg_last_error(void);
 int  lg_abi_version(void);

@@ -16,7 +16,7 @@ from typing import Dict, Optional
 
 import numpy as np
 
-LG_ABI_VERSION = 6
+LG_ABI_VERSION = 7
 LG_MAX_LIMBS, LG_MAX_CHAIN, LG_MAX_DOF = 4, 6, 12
 LG_MAX_LIMB_POINTS, LG_MAX_BASE_POINTS, LG_MAX_BODIES = 8, 4, 20
 LG_MAX_HEIGHT_POINTS, LG_ACTUATOR_FLOATS = 192, 972
@@ -208,6 +208,12 @@ def bind_prototypes(lib, prefix: str):
         "abi_version": ([], C.c_int),
         "sizeof": ([C.c_int], C.c_int),
     }
+    if prefix == "lg_":      # the fused actor is a product-only entry point (the oracle side of it is torch fp32)
+        lib.lg_policy_create.argtypes = [C.POINTER(i32), C.POINTER(_PF), C.POINTER(_PF), _PF, C.c_int, C.POINTER(vp)]
+        lib.lg_policy_create.restype = C.c_int
+        lib.lg_policy_destroy.argtypes, lib.lg_policy_destroy.restype = [vp], None
+        lib.lg_policy_act.argtypes = [vp, vp, vp, vp, i32, u64, i64, vp, i32, vp]
+        lib.lg_policy_act.restype = C.c_int
     for name, (args, res) in sig.items():
         fn = getattr(lib, prefix + name)
         fn.argtypes, fn.restype = args, res
@@ -220,7 +226,7 @@ def bind_prototypes(lib, prefix: str):
 
 EXPORTED_SYMBOLS = ["lg_create", "lg_destroy", "lg_bind", "lg_step", "lg_reset_idx", "lg_actuator_forward",
                     "lg_physics_substep", "lg_compute_observations_only", "lg_set_params", "lg_last_error",
-                    "lg_abi_version", "lg_sizeof"]
+                    "lg_abi_version", "lg_sizeof", "lg_policy_create", "lg_policy_destroy", "lg_policy_act"]
 
 
 def load_library():

@@ -16,6 +16,7 @@
 #include <new>
 
 #include "lg_device.h"
+#include "lg_policy.h"
 
 using namespace lg;
 
@@ -1077,7 +1078,85 @@ static void fill_args(const lg_sim *s, KArgs &a, int64_t step) {
 }
 template <class T> static int grid_for(int n_env_like) { return (n_env_like * T::K + LG_BLOCK - 1) / LG_BLOCK; }
 
+// ------------------------------------------------------------------ fused actor (lg_policy.h): host side
+struct lg_policy {
+    int32_t dims[5];
+    int     tiles[4];          // input tiles of layer 0, then hidden widths / 16
+    float  *d_w[4], *d_b[4], *d_std;
+    int     device;
+};
+// torch Linear [out,in] -> MFMA A-operand stream [out_tile][k_step = (t,r)][lane]: W[16o + (l&15)][16t + 4(l>>4) + r]
+static void policy_pack_layer(const float *W, const float *bias, int in_dim, int out_dim, int in_tiles, int out_tiles,
+                              float *w_packed, float *b_packed) {
+    for (int o = 0; o < out_tiles; o++) {
+        for (int t = 0; t < in_tiles; t++) for (int r = 0; r < 4; r++) for (int l = 0; l < 64; l++) {
+            int row = 16 * o + (l & 15), col = 16 * t + 4 * (l >> 4) + r;
+            w_packed[((size_t)(o * in_tiles + t) * 4 + r) * 64 + l] = (row < out_dim && col < in_dim) ? W[(size_t)row * in_dim + col] : 0.0f;
+        }
+        for (int r = 0; r < 4; r++) for (int l = 0; l < 64; l++) {       // D layout: lane l, reg r = row 16o + 4(l>>4) + r
+            int row = 16 * o + 4 * (l >> 4) + r;
+            b_packed[(o * 4 + r) * 64 + l] = row < out_dim ? bias[row] : 0.0f;
+        }
+    }
+}
+
 extern "C" {
+
+int lg_policy_create(const int32_t dims[5], const float *const weights[4], const float *const biases[4], const float *std,
+                     int device_id, lg_policy **out) {
+    if (!dims || !weights || !biases || !std || !out) return fail(-1, "null argument");
+    for (int i = 1; i <= 3; i++) if (dims[i] % 16 || dims[i] <= 0 || dims[i] > 512) return fail(-4, "hidden widths must be multiples of 16, <= 512");
+    if (dims[0] <= 0 || dims[0] > 256 || dims[4] <= 0 || dims[4] > 16) return fail(-4, "unsupported obs / action width");
+    HIP_TRY(hipSetDevice(device_id));
+    lg_policy *p = new (std::nothrow) lg_policy();
+    if (!p) return fail(-5, "out of host memory");
+    memcpy(p->dims, dims, sizeof p->dims); p->device = device_id;
+    for (int i = 0; i < 4; i++) { p->d_w[i] = nullptr; p->d_b[i] = nullptr; }
+    p->d_std = nullptr;
+    p->tiles[0] = (dims[0] + 15) / 16; p->tiles[1] = dims[1] / 16; p->tiles[2] = dims[2] / 16; p->tiles[3] = dims[3] / 16;
+    for (int i = 0; i < 4; i++) {
+        int in_t = p->tiles[i], out_t = (i < 3) ? p->tiles[i + 1] : 1;
+        size_t nw = (size_t)out_t * in_t * 4 * 64, nb = (size_t)out_t * 4 * 64;
+        float *hw = (float *)malloc(nw * 4), *hb = (float *)malloc(nb * 4);
+        policy_pack_layer(weights[i], biases[i], dims[i], dims[i + 1], in_t, out_t, hw, hb);
+        bool ok = hipMalloc(&p->d_w[i], nw * 4) == hipSuccess && hipMalloc(&p->d_b[i], nb * 4) == hipSuccess &&
+                  hipMemcpy(p->d_w[i], hw, nw * 4, hipMemcpyHostToDevice) == hipSuccess &&
+                  hipMemcpy(p->d_b[i], hb, nb * 4, hipMemcpyHostToDevice) == hipSuccess;
+        free(hw); free(hb);
+        if (!ok) { lg_policy_destroy(p); return fail(-10, "policy weight upload failed"); }
+    }
+    if (hipMalloc(&p->d_std, 16 * 4) != hipSuccess || hipMemcpy(p->d_std, std, dims[4] * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        lg_policy_destroy(p); return fail(-10, "policy std upload failed");
+    }
+    *out = p;
+    return 0;
+}
+
+void lg_policy_destroy(lg_policy *p) {
+    if (!p) return;
+    for (int i = 0; i < 4; i++) { if (p->d_w[i]) (void)hipFree(p->d_w[i]); if (p->d_b[i]) (void)hipFree(p->d_b[i]); }
+    if (p->d_std) (void)hipFree(p->d_std);
+    delete p;
+}
+
+int lg_policy_act(lg_policy *p, const float *obs, float *actions, float *mean, int32_t num_envs, uint64_t seed, int64_t step,
+                  const int64_t *step_counter, int32_t deterministic, void *stream) {
+    if (!p || !obs || !actions) return fail(-1, "null argument");
+    if (num_envs <= 0) return 0;
+    PolicyArgs a;
+    a.obs = obs; a.actions = actions; a.mean = mean; a.std = p->d_std; a.step_counter = step_counter; a.step = step; a.seed = seed;
+    a.num_envs = num_envs; a.num_obs = p->dims[0]; a.num_actions = p->dims[4]; a.deterministic = deterministic;
+    for (int i = 0; i < 4; i++) { a.w[i] = p->d_w[i]; a.b[i] = p->d_b[i]; }
+    dim3 g((num_envs + 15) / 16), b(64);
+    hipStream_t st = (hipStream_t)stream;
+    const int t0 = p->tiles[0], t1 = p->tiles[1], t2 = p->tiles[2], t3 = p->tiles[3];
+    if (t0 == 3 && t1 == 8 && t2 == 4 && t3 == 2) hipLaunchKernelGGL((k_policy_act<3, 8, 4, 2>), g, b, 0, st, a);            // flat: 48-128-64-32
+    else if (t0 == 15 && t1 == 32 && t2 == 16 && t3 == 8) hipLaunchKernelGGL((k_policy_act<15, 32, 16, 8>), g, b, 0, st, a);  // rough: 235-512-256-128
+    else if (t0 == 11 && t1 == 32 && t2 == 16 && t3 == 8) hipLaunchKernelGGL((k_policy_act<11, 32, 16, 8>), g, b, 0, st, a);  // cassie: 169-512-256-128
+    else return fail(-4, "actor widths are not one of the compiled-in shapes (48-128-64-32, 235/169-512-256-128)");
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
 
 const char *lg_last_error(void) { return g_err; }
 int lg_abi_version(void) { return LG_ABI_VERSION; }

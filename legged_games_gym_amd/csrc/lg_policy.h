@@ -1,0 +1,94 @@
+// lg_policy.h -- fused actor MLP + Gaussian sampling on the matrix cores (rollout-time policy forward).
+//
+// Stands in for rsl_rl ActorCritic.act() ([EXTERNAL]; dims from reference legged_robot_config.py:204-209 and
+// anymal_c_flat_config.py:62-65): a = actor(obs) + std * eps, actor = Linear/ELU x3 + Linear.
+//
+// One wave = 16 envs.  v_mfma_f32_16x16x4_f32 computes  D[out 16][env 16] += W[out][k 4] * X[k][env]:
+//   A operand (weights): lane l holds W[16*o + (l&15)][k_(l>>4)],   B operand (activations): lane l holds X[k_(l>>4)][env l&15],
+//   D: lane l holds rows 4*(l>>4)+r (r = 0..3) of column env l&15.
+// So register r of output tile t holds, on lane group g = l>>4, feature 16t + 4g + r of env l&15 -- which is exactly a
+// B operand if the next layer's K-steps are enumerated as (t, r) with k_g = 16t + 4g + r.  The host permutes the weight
+// columns accordingly (lg_policy_pack), hence activations never leave registers: no LDS, no transposes, no barriers.
+// Weights stream from L2 as one coalesced 256-B load per MFMA (the whole flat actor is 67 KB).
+#pragma once
+#include "lg_device.h"
+
+namespace lg {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+LG_DEV float elu1(float x) { return x > 0.0f ? x : (__builtin_amdgcn_exp2f(1.442695041f * x) - 1.0f); }
+
+// one layer: IN_T input tiles of 16 features (registers x[IN_T][4]) -> OUT_T output tiles
+template <int IN_T, int OUT_T, bool ACT>
+LG_DEV void mlp_layer(const float *__restrict__ w /* [OUT_T][IN_T*4][64] */, const float *__restrict__ b /* [OUT_T][4][64] */,
+                      const float (&x)[IN_T][4], float (&y)[OUT_T][4], int lane) {
+#pragma unroll
+    for (int o = 0; o < OUT_T; o++) {
+        f32x4 acc;
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[r] = b[(o * 4 + r) * 64 + lane];
+        const float *wo = w + (size_t)o * IN_T * 4 * 64 + lane;
+#pragma unroll
+        for (int t = 0; t < IN_T; t++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wo[(t * 4 + r) * 64], x[t][r], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; r++) y[o][r] = ACT ? elu1(acc[r]) : acc[r];
+    }
+}
+
+struct PolicyArgs {
+    const float *obs;      // [N, num_obs]
+    const float *w[4];     // packed weights per layer (lg_policy_pack)
+    const float *b[4];     // packed biases per layer
+    const float *std;      // [num_actions]
+    float *actions;        // [N, num_actions]  sampled
+    float *mean;           // [N, num_actions]  or null
+    const int64_t *step_counter;   // device counter (Philox stream), may be null
+    int64_t step;          // used when >= 0
+    uint64_t seed;
+    int32_t num_envs, num_obs, num_actions, deterministic;
+};
+
+template <int D0T, int D1T, int D2T, int D3T>     // layer widths in tiles of 16 (D0T = ceil(num_obs/16)); output = 1 tile
+__global__ void __launch_bounds__(64) k_policy_act(const PolicyArgs A) {
+    const int lane = threadIdx.x, g = lane >> 4;
+    int env = blockIdx.x * 16 + (lane & 15);
+    const bool live = env < A.num_envs;
+    if (!live) env = A.num_envs - 1;
+    // layer-0 B operands straight from global: k_g = 16t + 4g + r
+    float x0[D0T][4];
+    const float *o = A.obs + (size_t)env * A.num_obs;
+#pragma unroll
+    for (int t = 0; t < D0T; t++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) { int k = 16 * t + 4 * g + r; x0[t][r] = k < A.num_obs ? o[k] : 0.0f; }
+    float x1[D1T][4], x2[D2T][4], x3[D3T][4], y[1][4];
+    mlp_layer<D0T, D1T, true>(A.w[0], A.b[0], x0, x1, lane);
+    mlp_layer<D1T, D2T, true>(A.w[1], A.b[1], x1, x2, lane);
+    mlp_layer<D2T, D3T, true>(A.w[2], A.b[2], x2, x3, lane);
+    mlp_layer<D3T, 1, false>(A.w[3], A.b[3], x3, y, lane);
+    // lane (env, g) now holds mean[4g + r]; sample a = mean + std * eps  (Philox -> Box-Muller)
+    const int64_t step = A.step >= 0 ? A.step : (A.step_counter ? A.step_counter[0] + 1 : 0);
+    float u[4];
+    rand4(A.seed ^ 0x9E3779B97F4A7C15ull, env, step, 100 + g, 0, u);
+    float rad0 = sqrtf(-2.0f * __logf(fmaxf(u[0], 1e-12f))), rad1 = sqrtf(-2.0f * __logf(fmaxf(u[2], 1e-12f)));
+    float s0, c0, s1, c1;
+    __sincosf(6.2831853f * u[1], &s0, &c0);
+    __sincosf(6.2831853f * u[3], &s1, &c1);
+    float eps[4] = {rad0 * c0, rad0 * s0, rad1 * c1, rad1 * s1};
+    if (live) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            int a = 4 * g + r;
+            if (a < A.num_actions) {
+                float m = y[0][r];
+                if (A.mean) A.mean[(size_t)env * A.num_actions + a] = m;
+                A.actions[(size_t)env * A.num_actions + a] = A.deterministic ? m : m + A.std[a] * eps[r];
+            }
+        }
+    }
+}
+
+}  // namespace lg

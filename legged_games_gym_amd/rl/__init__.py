@@ -14,4 +14,12 @@ from .actor_critic import ActorCritic
 from .ppo import PPO, RolloutStorage
 from .runner import OnPolicyRunner
 
-__all__ = ["ActorCritic", "PPO", "RolloutStorage", "OnPolicyRunner"]
+
+
+def FusedActor(*args, **kwargs):
+    """Lazy import: the fused MFMA actor needs the HIP extension (GPU only)."""
+    from .fused_actor import FusedActor as _F
+    return _F(*args, **kwargs)
+
+
+__all__ = ["ActorCritic", "PPO", "RolloutStorage", "OnPolicyRunner", "FusedActor"]

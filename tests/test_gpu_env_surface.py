@@ -67,3 +67,33 @@ def test_bundled_runner_learns_a_few_iterations(tmp_path):
     assert path.endswith("model_2.pt")
     policy = runner.get_inference_policy(device=env.device)
     assert policy(env.get_observations()).shape == (128, 12)
+
+
+def test_fused_actor_matches_torch_forward():
+    """lg_policy_act (fp32 MFMA) vs the plain PyTorch fp32 forward of the same ActorCritic, all three compiled-in shapes."""
+    from legged_games_gym_amd.rl import ActorCritic, FusedActor
+    for n_obs, hidden in ((48, [128, 64, 32]), (235, [512, 256, 128]), (169, [512, 256, 128])):
+        torch.manual_seed(3)
+        ac = ActorCritic(n_obs, n_obs, 12, actor_hidden_dims=hidden, critic_hidden_dims=hidden).cuda()
+        with torch.no_grad():
+            ac.std.copy_(torch.linspace(0.3, 1.4, 12))
+        fa = FusedActor(ac, "cuda:0", seed=5)
+        obs = torch.randn(1000, n_obs, device="cuda") * 2.0            # 1000: not a multiple of 16 (tail wave)
+        with torch.no_grad():
+            want = ac.actor(obs)
+        actions, mean = fa.act_with_mean(obs)
+        actions, mean = actions.clone(), mean.clone()          # the wrapper reuses its output buffers
+        torch.cuda.synchronize()
+        scale = float(want.abs().max())
+        assert float((mean - want).abs().max()) < 2e-5 * max(1.0, scale), (n_obs, float((mean - want).abs().max()))
+        z = ((actions - mean) / ac.std.detach()).flatten()
+        assert abs(float(z.mean())) < 0.03 and abs(float(z.std()) - 1.0) < 0.03 and float(z.abs().max()) < 6.0
+        a2 = fa.act(obs).clone()
+        assert not torch.equal(a2, actions)                            # fresh noise per call
+        assert torch.allclose(fa.act_inference(obs), want, atol=2e-5 * max(1.0, scale))
+        with torch.no_grad():                                          # sync() re-uploads changed weights
+            ac.actor[0].weight.mul_(0.5)
+        fa.sync()
+        with torch.no_grad():
+            want2 = ac.actor(obs)
+        assert torch.allclose(fa.act_inference(obs), want2, atol=2e-5 * max(1.0, float(want2.abs().max())))
