@@ -36,7 +36,9 @@ def main():
     ap.add_argument("--num-envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--torch-policy", action="store_true", help="policy forward with torch ops instead of the fused MFMA actor kernel")
+    ap.add_argument("--policy", choices=["auto", "fused", "torch"], default="auto",
+                    help="auto: fused MFMA actor kernel for narrow nets (hidden <= 128, the flat config), torch/hipBLASLt otherwise")
+    ap.add_argument("--torch-policy", action="store_true", help="same as --policy torch")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one captured HIP graph per step")
     ap.add_argument("--event-steps", type=int, default=200, help="eager steps timed with HIP events for the roofline object")
     a = ap.parse_args()
@@ -50,8 +52,13 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        backend = os.environ.get("LG_BENCH_BACKEND", "nccl")     # "gloo": rehearsal of the N>1 path on a 1-GPU box
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)
+            dist.init_process_group(backend)
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
 
@@ -74,7 +81,9 @@ def main():
     policy = ActorCritic(env.num_obs, env.num_obs, env.num_actions, **pol).to(dev)
     with contextlib.redirect_stdout(io.StringIO()):
         obs, _ = env.reset()
-    if a.torch_policy:
+    use_torch = a.torch_policy or a.policy == "torch" or (a.policy == "auto" and max(pol["actor_hidden_dims"]) > 128)
+    a.torch_policy = use_torch
+    if use_torch:
         policy_act = policy.act
     else:
         from legged_games_gym_amd.rl import FusedActor
@@ -112,7 +121,7 @@ def main():
         torch.cuda.synchronize()
     finite = bool(torch.isfinite(env.obs_buf).all()) and bool(torch.isfinite(env.root_states).all())
     kern_ms = sum(s_.elapsed_time(e_) for s_, e_ in ev) / n_ev
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if (world == 1 or dist.get_backend() == "nccl") else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -122,6 +131,13 @@ def main():
         total_envs = a.num_envs * world
         value = total_envs * a.steps / elapsed
         bpe = BYTES_PER_ENV_STEP.get(a.task, 4022)
+        traffic = None                      # PMC bytes per k_step launch from the committed rocprofv3 passes (same workload only)
+        try:
+            pm = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_summary.json")))
+            if a.task == "anymal_c_flat" and a.num_envs == 4096:
+                traffic = pm["k_step_traffic_bytes"]["fetch_doubled_sum"]
+        except Exception:
+            pass
         achieved = bpe * a.num_envs / (kern_ms * 1e-3) / 1e9
         out = {
             "metric": "env-steps/sec (whole node), ANYmal-C flat 4096 envs/GPU" if a.task == "anymal_c_flat" else f"env-steps/sec (whole node), {a.task}",
@@ -136,7 +152,7 @@ def main():
                        "launch": "eager" if a.no_graph else "one captured HIP graph per policy step (policy + lg_step)",
                        "policy": "torch ops (hipBLASLt)" if a.torch_policy else "fused MFMA actor kernel (lg_policy_act, v_mfma_f32_16x16x4_f32)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "k_step<AnymalTraits,NET,plane>" if a.task != "cassie" else "k_step<CassieTraits>",
+                         "traffic": traffic, "traffic_source": "profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, 2*FETCH+WRITE KiB)" if traffic else None, "kernel": "k_step<AnymalTraits,NET,plane>" if a.task != "cassie" else "k_step<CassieTraits>",
                          "kernel_ms": kern_ms, "kernel_ms_method": f"HIP events around {n_ev} eager lg_step launches (k_step + k_extras) right after the timed region",
                          "algorithmic_bytes_per_env_step": bpe,
                          "note": "fused step is VALU/latency-bound at 4096 envs (256 waves on 1024 SIMDs); see DESIGN.md"},
