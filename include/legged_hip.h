@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LG_ABI_VERSION        7
+#define LG_ABI_VERSION        8
 
 #define LG_MAX_LIMBS          4
 #define LG_MAX_CHAIN          6
@@ -181,6 +181,11 @@ int  lg_actuator_forward(lg_sim *sim, const float *pos_err, const float *vel, fl
                          float *hidden, float *cell, int32_t rows, void *stream);       /* anymal.py:71-78 */
 int  lg_physics_substep(lg_sim *sim, const float *torques, int32_t write_contacts, void *stream); /* legged_robot.py:92-96 */
 int  lg_compute_observations_only(lg_sim *sim, int64_t common_step_counter, void *stream);        /* legged_robot.py:212-230 */
+
+/* Redirect where the next lg_step / lg_compute_observations_only writes observations ([N,num_obs] device buffer).
+ * The reference re-creates obs_buf every step (legged_robot.py:215) and rsl_rl keeps a reference to the previous
+ * one until process_env_step; the Python surface therefore ping-pongs two buffers through this call. */
+int  lg_set_obs_buffer(lg_sim *sim, float *obs_buf);
 
 /* Update params that the Python surface may change between steps
  * (command ranges by the curriculum, legged_robot.py:471-483). */

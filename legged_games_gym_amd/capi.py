@@ -16,7 +16,7 @@ from typing import Dict, Optional
 
 import numpy as np
 
-LG_ABI_VERSION = 7
+LG_ABI_VERSION = 8
 LG_MAX_LIMBS, LG_MAX_CHAIN, LG_MAX_DOF = 4, 6, 12
 LG_MAX_LIMB_POINTS, LG_MAX_BASE_POINTS, LG_MAX_BODIES = 8, 4, 20
 LG_MAX_HEIGHT_POINTS, LG_ACTUATOR_FLOATS = 192, 972
@@ -204,6 +204,7 @@ def bind_prototypes(lib, prefix: str):
         "physics_substep": ([vp, vp, i32, vp], C.c_int),
         "compute_observations_only": ([vp, i64, vp], C.c_int),
         "set_params": ([vp, C.POINTER(lg_params)], C.c_int),
+        "set_obs_buffer": ([vp, vp], C.c_int),
         "last_error": ([], C.c_char_p),
         "abi_version": ([], C.c_int),
         "sizeof": ([C.c_int], C.c_int),
@@ -226,7 +227,7 @@ def bind_prototypes(lib, prefix: str):
 
 EXPORTED_SYMBOLS = ["lg_create", "lg_destroy", "lg_bind", "lg_step", "lg_reset_idx", "lg_actuator_forward",
                     "lg_physics_substep", "lg_compute_observations_only", "lg_set_params", "lg_last_error",
-                    "lg_abi_version", "lg_sizeof", "lg_policy_create", "lg_policy_destroy", "lg_policy_act"]
+                    "lg_abi_version", "lg_sizeof", "lg_set_obs_buffer", "lg_policy_create", "lg_policy_destroy", "lg_policy_act"]
 
 
 def load_library():
@@ -292,6 +293,9 @@ class Sim:
 
     def compute_observations_only(self, common_step_counter, stream=0):
         self._check(self._fn("compute_observations_only")(self.handle, int(common_step_counter), stream))
+
+    def set_obs_buffer(self, ptr: int):
+        self._check(self._fn("set_obs_buffer")(self.handle, ptr))
 
     def set_params(self, params: lg_params):
         self.params = params

@@ -133,7 +133,7 @@ LG_DEV bool solve6(const AI &I, const float *b, float *x) {
             m[i][j] = I.A[ix[i][j]]; m[i + 3][j + 3] = I.M[ix[i][j]];
             m[i][j + 3] = I.H[3 * i + j]; m[j + 3][i] = I.H[3 * i + j];
         }
-    float Lm[6][6], D[6];
+    float Lm[6][6], D[6], rD[6];
     bool ok = true;
 #pragma unroll
     for (int j = 0; j < 6; j++) {
@@ -142,12 +142,13 @@ LG_DEV bool solve6(const AI &I, const float *b, float *x) {
         for (int k = 0; k < j; k++) d -= Lm[j][k] * Lm[j][k] * D[k];
         ok = ok && (d > 0.0f);
         D[j] = d;
+        rD[j] = __builtin_amdgcn_rcpf(d);            // 6 v_rcp instead of 21 divisions (1 ulp)
 #pragma unroll
         for (int i = j + 1; i < 6; i++) {
             float v = m[i][j];
 #pragma unroll
             for (int k = 0; k < j; k++) v -= Lm[i][k] * Lm[j][k] * D[k];
-            Lm[i][j] = v / d;
+            Lm[i][j] = v * rD[j];
         }
     }
     float y[6];
@@ -157,7 +158,7 @@ LG_DEV bool solve6(const AI &I, const float *b, float *x) {
         for (int k = 0; k < i; k++) v -= Lm[i][k] * y[k];
         y[i] = v; }
 #pragma unroll
-    for (int i = 0; i < 6; i++) y[i] /= D[i];
+    for (int i = 0; i < 6; i++) y[i] *= rD[i];
 #pragma unroll
     for (int i = 5; i >= 0; i--) { float v = y[i];
 #pragma unroll

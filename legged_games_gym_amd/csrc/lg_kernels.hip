@@ -118,7 +118,7 @@ LG_DEV void contact_evaluate(Contact &c, const lg_params &P, float kn, float mu,
 }
 
 template <class T, bool HF>
-LG_DEV void physics_substep(const KArgs &A, const float *tab, float (&root)[13], float (&q)[T::L], float (&qd)[T::L],
+LG_DEV void physics_substep(const KArgs &A, const float *tab, int lane_k, float (&root)[13], float (&q)[T::L], float (&qd)[T::L],
                             const float (&tau)[T::L], float base_mass, float mu,
                             float (&Frep)[T::NREP][3], float (&Fbase)[3]) {
     constexpr int K = T::K, L = T::L, NPT = T::NPT, NBASE = T::NBASE;
@@ -160,18 +160,24 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, float (&root)[13],
     S6 C[L];
     AI I0[L], I0b;
     S6 p0[L], p0b;
-    Contact cb[NBASE], cl[NPT];
+    Contact cb, cl[NPT];
     {
         float sc = base_mass / A.base.mass, Il[6];
 #pragma unroll
         for (int i = 0; i < 6; i++) Il[i] = A.base.inertia[i] * sc;
         body_terms(base_mass, v3(A.base.com[0], A.base.com[1], A.base.com[2]), Il, R0, w0, v0, I0b, p0b);
+        // base collision points are split over the env's lanes (lane i owns point i); their inertia / bias contribution
+        // joins the lane's limb contribution before the butterfly, their force is butterfly-summed afterwards
+        static_assert(NBASE <= K, "one base point per lane at most");
+        {
+            float bp[4] = {A.base.pts[0][0], A.base.pts[0][1], A.base.pts[0][2], A.base.pts[0][3]};
 #pragma unroll
-        for (int i = 0; i < NBASE; i++) {
-            V3 r = mul(R0, v3(A.base.pts[i][0], A.base.pts[i][1], A.base.pts[i][2]));
+            for (int i = 1; i < NBASE; i++) if (lane_k == i) { bp[0] = A.base.pts[i][0]; bp[1] = A.base.pts[i][1]; bp[2] = A.base.pts[i][2]; bp[3] = A.base.pts[i][3]; }
+            V3 r = mul(R0, v3(bp[0], bp[1], bp[2]));
             float h; V3 n;
             ground_query<HF>(A, root[0] + r.x, root[1] + r.y, h, n);
-            contact_setup(cb[i], P, mu, r, n, A.base.pts[i][3] - (root[2] + r.z - h) * n.z, v0 + cross(w0, r), v3(Fbase[0], Fbase[1], Fbase[2]));
+            contact_setup(cb, P, mu, r, n, bp[3] - (root[2] + r.z - h) * n.z, v0 + cross(w0, r), v3(Fbase[0], Fbase[1], Fbase[2]));
+            cb.on = cb.on && (lane_k < NBASE);
         }
     }
     {
@@ -188,7 +194,7 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, float (&root)[13],
             const M3 Rz = mul(Rpar, Rfix);
             ax[j] = mul(Rz, v3(tj[J_AXIS], tj[J_AXIS + 1], tj[J_AXIS + 2]));
             float sn, cs;
-            sincosf(q[j], &sn, &cs);
+            __sincosf(q[j], &sn, &cs);               // v_sin/v_cos (|q| stays within a few rad; abs err ~1e-6)
             M3 Rj;
 #pragma unroll
             for (int c = 0; c < 3; c++) {
@@ -246,23 +252,21 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, float (&root)[13],
                     u += -P.limit_stiffness * viol - kl * qd[j];
                 }
             }
-            Dinv[j] = 1.0f / D; uu[j] = u;
+            Dinv[j] = __builtin_amdgcn_rcpf(D); uu[j] = u;
             Ia = IA;
             ai_add_rank1(Ia, -Dinv[j], U[j].w, U[j].v);
             pa = (pA + ai_mul(Ia, C[j])) + U[j] * (u * Dinv[j]);
             ai_shift(Ia, pa, db[j]);                 // to the parent's origin (the base origin for j == 0)
         }
+        contact_assemble(cb, P, kn, Ia, pa);      // this lane's base point (about the base origin, like Ia after the shift)
         group_sum<K>(Ia, pa);                     // (limb0+limb1)+(limb2+limb3) on every lane of the env
         AI IAb = I0b; S6 pAb = p0b;
-#pragma unroll
-        for (int i = 0; i < NBASE; i++) contact_assemble(cb[i], P, kn, IAb, pAb);
         ai_add(IAb, Ia); pAb = pAb + pa;
         float rhs[6] = {-pAb.w.x, -pAb.w.y, -pAb.w.z, -pAb.v.x, -pAb.v.y, -pAb.v.z}, a0[6];
         bool ok = solve6(IAb, rhs, a0);
         if (!ok) { a0[0] = a0[1] = a0[2] = a0[3] = a0[4] = a0[5] = 0.0f; }
         acc0.w = v3(a0[0], a0[1], a0[2]); acc0.v = v3(a0[3], a0[4], a0[5]);
-#pragma unroll
-        for (int i = 0; i < NBASE; i++) contact_evaluate(cb[i], P, kn, mu, acc0);
+        contact_evaluate(cb, P, kn, mu, acc0);
         S6 a = acc0;
 #pragma unroll
         for (int j = 0; j < L; j++) {
@@ -306,12 +310,7 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, float (&root)[13],
         for (int i = 0; i < NPT; i++) if (T::pt_rep(i) == r) f = f + cl[i].f;
         Frep[r][0] = f.x; Frep[r][1] = f.y; Frep[r][2] = f.z;
     }
-    {
-        V3 f = v3(0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < NBASE; i++) f = f + cb[i].f;
-        Fbase[0] = f.x; Fbase[1] = f.y; Fbase[2] = f.z;
-    }
+    Fbase[0] = group_sum<K>(cb.f.x); Fbase[1] = group_sum<K>(cb.f.y); Fbase[2] = group_sum<K>(cb.f.z);
 }
 
 // ------------------------------------------------------------------ torques (legged_robot.py:371-395)
@@ -564,7 +563,7 @@ __global__ void __launch_bounds__(LG_BLOCK) k_step(const KArgs A) {
         } else {
             pd_torques<L>(P, tab, act, q, qd, last_qd, tau);
         }
-        physics_substep<T, HF>(A, tab, root, q, qd, tau, base_mass, mu, Frep, Fbase);
+        physics_substep<T, HF>(A, tab, k, root, q, qd, tau, base_mass, mu, Frep, Fbase);
     }
 
     // =====================  post_physics_step  (legged_robot.py:106-137)  =====================
@@ -939,7 +938,7 @@ __global__ void __launch_bounds__(LG_BLOCK) k_physics(const KArgs A, const float
         Fbase[0] = c0[0]; Fbase[1] = c0[1]; Fbase[2] = c0[2];
     }
     write_contacts = 1;           // the net contact forces also seed the next sub-step's friction estimate
-    physics_substep<T, HF>(A, tab, root, q, qd, tau, base_mass, mu, Frep, Fbase);
+    physics_substep<T, HF>(A, tab, k, root, q, qd, tau, base_mass, mu, Frep, Fbase);
     if (!live) return;
 #pragma unroll
     for (int j = 0; j < L; j++) { B.dof_state[2 * (d0 + j)] = q[j]; B.dof_state[2 * (d0 + j) + 1] = qd[j]; }
@@ -1214,6 +1213,12 @@ int lg_bind(lg_sim *s, const lg_buffers *b) {
     if (s->P.terrain_type == LG_TERRAIN_HEIGHTFIELD && !b->height_samples) return fail(-6, "height_samples missing");
     if (s->P.terrain_curriculum && (!b->terrain_levels || !b->terrain_types || !b->terrain_origins)) return fail(-6, "terrain curriculum buffers missing");
     s->B = *b; s->bound = true;
+    return 0;
+}
+
+int lg_set_obs_buffer(lg_sim *s, float *obs_buf) {
+    if (!s || !obs_buf) return fail(-1, "null argument");
+    s->B.obs_buf = obs_buf;
     return 0;
 }
 

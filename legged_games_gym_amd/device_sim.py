@@ -53,6 +53,11 @@ class DeviceSim:
     def _stream(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream
 
+    def set_obs_output(self, obs: torch.Tensor):
+        """Where the next step writes its observations (ping-pong, see LeggedRobot.step)."""
+        self._obs_out = obs
+        self.sim.set_obs_buffer(obs.data_ptr())
+
     def step(self, actions: torch.Tensor, counter: int):
         if actions.dtype != torch.float32 or not actions.is_contiguous() or actions.device != self.device:
             actions = actions.to(device=self.device, dtype=torch.float32).contiguous()

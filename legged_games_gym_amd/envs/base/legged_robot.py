@@ -49,6 +49,11 @@ class LeggedRobot(BaseTask):
     def step(self, actions):
         """One policy step for all envs (reference :80-104), a single fused launch."""
         self.common_step_counter += 1                     # :115 (the kernel needs the incremented value)
+        # The reference builds a NEW obs_buf every step (:215) and rsl_rl's PPO.act keeps a reference to the previous one
+        # until process_env_step: alternate between two buffers so the tensor returned last step is not overwritten.
+        self._obs_flip ^= 1
+        self.obs_buf = self._obs_pair[self._obs_flip]
+        self._sim.set_obs_output(self.obs_buf)
         self._sim.step(actions, self.common_step_counter)
         return self.obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf, self.extras
 
@@ -61,6 +66,7 @@ class LeggedRobot(BaseTask):
         The step counter lives on the device while replaying (``lg_step(..., -1)``), the host copy is
         advanced alongside.  ``policy_act`` must be capturable (no host syncs) and read ``self.obs_buf``."""
         sim = self._sim
+        sim.set_obs_output(self.obs_buf)                  # single fixed buffer while replaying (the policy reads it inside the graph)
         sim.buf["step_counter"].fill_(self.common_step_counter)
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
@@ -117,6 +123,7 @@ class LeggedRobot(BaseTask):
 
     def compute_observations(self):
         """Recompute obs_buf from the current state (reference :212-230)."""
+        self._sim.set_obs_output(self.obs_buf)
         self._sim.compute_observations_only(self.common_step_counter)
 
     # ------------------------------------------------------------------ creation
@@ -255,6 +262,8 @@ class LeggedRobot(BaseTask):
         self.base_quat = self.root_states[:, 3:7]
         self.contact_forces = b["contact_forces"]
         self.obs_buf, self.rew_buf = b["obs_buf"], b["rew_buf"]
+        self._obs_pair = (b["obs_buf"], torch.zeros_like(b["obs_buf"]))
+        self._obs_flip = 0
         self.reset_buf, self.time_out_buf = b["reset_buf"], b["time_out_buf"]
         self.reset_buf.fill_(True)                                   # base_task.py:73 starts at ones
         self.episode_length_buf = b["episode_length_buf"]

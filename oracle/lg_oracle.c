@@ -405,15 +405,19 @@ static void physics_substep_env(const lgo_sim *s, int e, const float *tau, int w
     for (int pass = 0; pass < LG_CONTACT_PASSES; pass++) {
         ai6 IA[NB]; sv6 pA[NB];
         for (int b = 0; b <= nd; b++) { IA[b] = I0[b]; pA[b] = p0[b]; }
+        ai6 IBp[LG_MAX_LIMBS]; sv6 pBp[LG_MAX_LIMBS];     /* base point i's terms ride with limb i (HIP: lane i owns base point i) */
+        for (int k = 0; k < K; k++) { ai_zero(&IBp[k]); pBp[k].w = V(0, 0, 0); pBp[k].v = V(0, 0, 0); }
         for (int i = 0; i < nc; i++) if (ct[i].on) {
             contact_t *c = &ct[i];
             float vn = dot(c->n, c->vc);
             v3 vt = sub(c->vc, scl(c->n, vn));
             v3 f = sub(scl(c->n, P->contact_stiffness * c->depth - c->kn * vn), scl(vt, c->bt));
-            ai_add_point(&IA[c->body], dt * c->bt, c->r);
-            ai_add_rank1(&IA[c->body], dt * (c->kn - c->bt), cross(c->r, c->n), c->n);
-            pA[c->body].w = sub(pA[c->body].w, cross(c->r, f));
-            pA[c->body].v = sub(pA[c->body].v, f);
+            ai6 *It = (c->body == 0) ? &IBp[i] : &IA[c->body];      /* base points are the first contacts: index i = point i */
+            sv6 *pt_ = (c->body == 0) ? &pBp[i] : &pA[c->body];
+            ai_add_point(It, dt * c->bt, c->r);
+            ai_add_rank1(It, dt * (c->kn - c->bt), cross(c->r, c->n), c->n);
+            pt_->w = sub(pt_->w, cross(c->r, f));
+            pt_->v = sub(pt_->v, f);
         }
         for (int k = 0; k < K; k++) for (int j = L - 1; j >= 0; j--) {
             int d = k * L + j, b = 1 + d, par = (j == 0) ? 0 : b - 1;
@@ -445,7 +449,10 @@ static void physics_substep_env(const lgo_sim *s, int e, const float *tau, int w
         }
         {   /* base: (I0 + contacts) + ((l0+l1)+(l2+l3)) */
             ai6 acc_I[LG_MAX_LIMBS]; sv6 acc_p[LG_MAX_LIMBS];
-            for (int k = 0; k < K; k++) { acc_I[k] = IA[1 + k * L]; acc_p[k] = pA[1 + k * L]; }
+            for (int k = 0; k < K; k++) {
+                acc_I[k] = IA[1 + k * L]; acc_p[k] = pA[1 + k * L];
+                ai_add(&acc_I[k], &IBp[k]); acc_p[k] = sadd(acc_p[k], pBp[k]);
+            }
             for (int stride = 1; stride < K; stride *= 2)
                 for (int k = 0; k + stride < K; k += 2 * stride) { ai_add(&acc_I[k], &acc_I[k + stride]); acc_p[k] = sadd(acc_p[k], acc_p[k + stride]); }
             ai_add(&IA[0], &acc_I[0]); pA[0] = sadd(pA[0], acc_p[0]);
@@ -855,6 +862,7 @@ int lgo_create(const lg_params *params, const lg_robot_model *model, const float
 void lgo_destroy(lgo_sim *s) { free(s); }
 int lgo_bind(lgo_sim *s, const lg_buffers *b) { s->B = *b; return 0; }
 int lgo_set_params(lgo_sim *s, const lg_params *p) { s->P = *p; return 0; }
+int lgo_set_obs_buffer(lgo_sim *s, float *obs) { if (!s || !obs) return -1; s->B.obs_buf = obs; return 0; }
 int lgo_set_threads(lgo_sim *s, int n) { s->threads = n < 1 ? 1 : n; return 0; }
 
 int lgo_step(lgo_sim *s, const float *actions, int64_t step, void *stream) {

@@ -97,3 +97,16 @@ def test_fused_actor_matches_torch_forward():
         with torch.no_grad():
             want2 = ac.actor(obs)
         assert torch.allclose(fa.act_inference(obs), want2, atol=2e-5 * max(1.0, float(want2.abs().max())))
+
+
+def test_step_returns_a_fresh_observation_tensor_like_the_reference():
+    """legged_robot.py:215 re-creates obs_buf each step; rsl_rl's PPO.act holds the previous tensor by reference until
+    process_env_step.  The obs returned by step t must therefore survive step t+1 untouched."""
+    env, _ = _env()
+    obs0, _ = env.reset()
+    keep = obs0.clone()
+    obs1, *_ = env.step(torch.randn(64, 12, device="cuda"))
+    assert obs1.data_ptr() != obs0.data_ptr() and torch.equal(obs0, keep) and obs1 is env.obs_buf is env.get_observations()
+    keep1 = obs1.clone()
+    obs2, *_ = env.step(torch.randn(64, 12, device="cuda"))
+    assert torch.equal(obs1, keep1) and not torch.equal(obs2, obs1)
