@@ -54,6 +54,7 @@ struct KArgs {                 // passed by value: lives in the kernarg segment 
     const int32_t *env_ids;    // reset kernel only
     int32_t    count;
     uint32_t   penalised_mask, termination_mask;
+    unsigned int *done_counter;   // workgroup ticket of k_step (zeroed at create, self-resetting)
     int64_t    step;
 };
 
@@ -470,6 +471,29 @@ template <class T> LG_DEV void stage_limb_table(const KArgs &A, float *lds_tab) 
     __syncthreads();
 }
 
+// ------------------------------------------------------------------ extras["episode"] finisher (legged_robot.py:179-188)
+LG_DEV void finish_extras(const KArgs &A, int t, int64_t step_used, bool publish_step) {
+    const lg_params &P = A.P;
+    const int R = P.num_reward_slots;
+    if (publish_step && t == 0 && A.B.step_counter) A.B.step_counter[0] = step_used;
+    // accumulators were updated with device-scope atomics by other workgroups: read them past the L1 (sc1 loads)
+    float cnt = __hip_atomic_load(A.B.extras_accum + R, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    float v = (t < R) ? __hip_atomic_load(A.B.extras_accum + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
+    __syncthreads();
+    if (t < R) {
+        if (cnt > 0.0f) A.B.episode_means[t] = v / cnt / P.max_episode_length_s;
+        __hip_atomic_store(A.B.extras_accum + t, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (t == R) __hip_atomic_store(A.B.extras_accum + R, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (P.terrain_curriculum && A.B.terrain_levels) {
+        float acc = 0.0f;
+        for (int e = t; e < P.num_envs; e += 64)
+            acc += (float)__hip_atomic_load(A.B.terrain_levels + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (t == 0) A.B.episode_means[R] = acc / (float)P.num_envs;
+    }
+}
 // ------------------------------------------------------------------ THE fused policy-step kernel
 template <class T, bool NET, bool HF>
 __global__ void __launch_bounds__(LG_BLOCK) k_step(const KArgs A) {
@@ -731,7 +755,7 @@ __global__ void __launch_bounds__(LG_BLOCK) k_step(const KArgs A) {
         int level = 0; bool level_changed = false;
         reset_values<T>(A, tab, e, k, step, root, q, qd, cmd, origin, level, level_changed);
         if (writer && level_changed) {
-            B.terrain_levels[e] = level;
+            __hip_atomic_store(B.terrain_levels + e, level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // read by the finisher
             B.env_origins[(size_t)e * 3] = origin[0]; B.env_origins[(size_t)e * 3 + 1] = origin[1]; B.env_origins[(size_t)e * 3 + 2] = origin[2];
         }
         fat = 0.0f; ep_len = 0;     // the actuator state of reset envs is zeroed at write-back (anymal.py:59-60)
@@ -789,6 +813,20 @@ __global__ void __launch_bounds__(LG_BLOCK) k_step(const KArgs A) {
             B.episode_length_buf[e] = ep_len;
         }
     }
+    // ---- the workgroup that finishes last turns the accumulated sums into extras["episode"] (was a second launch).
+    // Its inputs are device-scope atomics (performed at the memory side: no cache write-back / invalidate is needed, and an
+    // agent-scope release fence per workgroup measured +6 us); the ticket is taken after this wave's own memory operations
+    // have drained (s_waitcnt vmcnt(0)), and the finisher reads with device-scope (L1-bypassing) loads.
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int ticket = atomicAdd(A.done_counter, 1u);
+        s_last = (ticket == gridDim.x - 1);
+        if (s_last) *A.done_counter = 0u;          // nothing else touches it until the next launch on this stream
+    }
+    __syncthreads();
+    if (s_last) finish_extras(A, threadIdx.x, step, true);
 }
 
 // ------------------------------------------------------------------ reset_idx on an id list (base_task.py:114-118)
@@ -856,26 +894,8 @@ __global__ void __launch_bounds__(LG_BLOCK) k_reset(const KArgs A) {
 // One wave, launched right behind k_step / k_reset on the same stream: turns the accumulated sums + count into the
 // means the reference logs (kept stale when nothing reset, quirk Q4), re-zeroes the accumulator, and refreshes the
 // mean terrain level.  Keeps env.step() free of per-step torch kernels and host syncs.
-__global__ void __launch_bounds__(64) k_extras(const KArgs A) {
-    const lg_params &P = A.P;
-    const int R = P.num_reward_slots, t = threadIdx.x;
-    if (A.count < 0 && t == 0 && A.B.step_counter)      // behind k_step: publish the step value it used
-        A.B.step_counter[0] = A.step >= 0 ? A.step : A.B.step_counter[0] + 1;
-    float cnt = A.B.extras_accum[R];
-    float v = (t < R) ? A.B.extras_accum[t] : 0.0f;
-    __syncthreads();
-    if (t < R) {
-        if (cnt > 0.0f) A.B.episode_means[t] = v / cnt / P.max_episode_length_s;
-        A.B.extras_accum[t] = 0.0f;
-    }
-    if (t == R) A.B.extras_accum[R] = 0.0f;
-    if (P.terrain_curriculum && A.B.terrain_levels) {
-        float acc = 0.0f;
-        for (int e = t; e < P.num_envs; e += 64) acc += (float)A.B.terrain_levels[e];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-        if (t == 0) A.B.episode_means[R] = acc / (float)P.num_envs;
-    }
+__global__ void __launch_bounds__(64) k_extras(const KArgs A) {        // behind k_reset (and available stand-alone)
+    finish_extras(A, threadIdx.x, A.step, false);
 }
 
 // ------------------------------------------------------------------ sub-path kernels (parity tests drive these)
@@ -998,6 +1018,7 @@ struct lg_sim {
     bool           has_net, bound;
     float         *d_limb_table;
     float         *d_weights;
+    unsigned int  *d_done;
 };
 
 template <class T> static int check_topology(const lg_robot_model *m) {
@@ -1073,7 +1094,7 @@ static int upload_tables(lg_sim *s) {
 static void fill_args(const lg_sim *s, KArgs &a, int64_t step) {
     a.P = s->P; a.B = s->B; a.base = s->base; a.limb_table = s->d_limb_table; a.weights = s->d_weights;
     a.actions_in = nullptr; a.env_ids = nullptr; a.count = 0; a.step = step;
-    a.penalised_mask = s->M.penalised_mask; a.termination_mask = s->M.termination_mask;
+    a.penalised_mask = s->M.penalised_mask; a.termination_mask = s->M.termination_mask; a.done_counter = s->d_done;
 }
 template <class T> static int grid_for(int n_env_like) { return (n_env_like * T::K + LG_BLOCK - 1) / LG_BLOCK; }
 
@@ -1179,7 +1200,8 @@ int lg_create(const lg_params *params, const lg_robot_model *model, const float 
     lg_sim *s = new (std::nothrow) lg_sim();
     if (!s) return fail(-5, "out of host memory");
     s->P = *params; s->M = *model; s->kind = kind; s->device = device_id; s->bound = false;
-    s->has_net = actuator_weights != nullptr; s->d_weights = nullptr; s->d_limb_table = nullptr;
+    s->has_net = actuator_weights != nullptr; s->d_weights = nullptr; s->d_limb_table = nullptr; s->d_done = nullptr;
+    if (hipMalloc(&s->d_done, sizeof(unsigned int)) != hipSuccess || hipMemset(s->d_done, 0, sizeof(unsigned int)) != hipSuccess) { delete s; return fail(-10, "hipMalloc failed"); }
     memset(&s->B, 0, sizeof s->B);
     if (hipMalloc(&s->d_limb_table, sizeof(float) * LG_MAX_LIMBS * (LG_MAX_CHAIN * LG_JS + 4 * LG_MAX_LIMB_POINTS + 1)) != hipSuccess) { delete s; return fail(-10, "hipMalloc failed"); }
     if (s->has_net) {
@@ -1198,6 +1220,7 @@ void lg_destroy(lg_sim *s) {
     if (!s) return;
     if (s->d_limb_table) (void)hipFree(s->d_limb_table);
     if (s->d_weights) (void)hipFree(s->d_weights);
+    if (s->d_done) (void)hipFree(s->d_done);
     delete s;
 }
 
@@ -1248,8 +1271,6 @@ int lg_step(lg_sim *s, const float *actions, int64_t common_step_counter, void *
         if (!hf) hipLaunchKernelGGL((k_step<CassieTraits, false, false>), g, b, 0, st, a);
         else hipLaunchKernelGGL((k_step<CassieTraits, false, true>), g, b, 0, st, a);
     }
-    a.count = -1;
-    hipLaunchKernelGGL(k_extras, dim3(1), dim3(64), 0, st, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -104,13 +104,10 @@ class LeggedRobot(BaseTask):
         if self.cfg.commands.curriculum:
             self.extras["episode"]["max_command_x"] = self.command_ranges["lin_vel_x"][1]
 
-    def _refresh_extras(self, force_ids=None):
-        """extras["episode"] / extras["time_outs"] (:179-191).  The means are computed by the library
-        (k_extras) into ``episode_means``; the dict holds 0-dim views, so no torch kernel and no host
-        sync happens here.  They stay stale on steps without resets (quirk Q4)."""
-        return
-
     def _init_extras(self):
+        """extras["episode"] / extras["time_outs"] (:179-191).  The means are computed by the library (the last workgroup
+        of k_step / k_extras) into ``episode_means``; the dict holds 0-dim views, so step() issues no torch kernel and
+        no host sync for them.  They stay stale on steps without resets (quirk Q4)."""
         ep = self.extras.setdefault("episode", {})
         for i, name in enumerate(self.reward_names_all):
             ep["rew_" + name] = self._episode_means[i]

@@ -110,3 +110,29 @@ def test_step_returns_a_fresh_observation_tensor_like_the_reference():
     keep1 = obs1.clone()
     obs2, *_ = env.step(torch.randn(64, 12, device="cuda"))
     assert torch.equal(obs1, keep1) and not torch.equal(obs2, obs1)
+
+
+def test_train_then_headless_play_resumes_from_checkpoint(tmp_path, monkeypatch):
+    """scripts/train.py -> scripts/play.py flow (reference train.py:39-43, play.py:42-80): run dir naming, model_<it>.pt,
+    get_load_path picking the latest run / checkpoint, inference policy driving the env."""
+    import legged_games_gym_amd as pkg
+    from legged_games_gym_amd.utils import task_registry as tr_mod
+    from legged_games_gym_amd.envs import task_registry
+    from legged_games_gym_amd.utils import get_args
+    from legged_games_gym_amd.scripts.play import play
+    monkeypatch.setattr(tr_mod, "LEGGED_GYM_ROOT_DIR", str(tmp_path))       # logs/<experiment>/<date>_<run>/ under tmp
+    args = get_args(["--task", "anymal_c_flat", "--num_envs", "64", "--headless", "--sim_device", "cuda:0", "--rl_device", "cuda:0",
+                     "--max_iterations", "1"])
+    env, _ = task_registry.make_env("anymal_c_flat", args)
+    runner, cfg = task_registry.make_alg_runner(env, "anymal_c_flat", args)
+    runner.learn(1)
+    import os
+    root = tmp_path / "logs" / "flat_anymal_c"
+    runs = os.listdir(root)
+    assert len(runs) == 1 and sorted(os.listdir(root / runs[0])) == ["model_0.pt", "model_1.pt"]
+    env2 = play(get_args(["--task", "anymal_c_flat", "--headless", "--sim_device", "cuda:0", "--rl_device", "cuda:0"]), steps=5)
+    assert env2.num_envs == 50 and not env2.cfg.noise.add_noise and torch.isfinite(env2.obs_buf).all()
+    # restore the registered (shared, mutated-in-place like the reference) configs for the other tests
+    c, t = task_registry.get_cfgs("anymal_c_flat")
+    c.env.num_envs, c.noise.add_noise, c.domain_rand.randomize_friction, c.domain_rand.push_robots = 4096, True, True, True
+    t.runner.resume = False

@@ -272,3 +272,19 @@ def test_full_size_invariants_4096():
     mass = robot.total_mass + dm
     assert np.median(np.abs(fz[up] / (mass[up] * 9.81) - 1.0)) < 0.02
     assert np.abs(get(d, "obs_buf")).max() <= 100.0
+
+
+@pytest.mark.parametrize("N", [1, 2, 3, 17])
+def test_tiny_and_ragged_env_counts(N):
+    """Partial waves: lanes beyond the last env must neither write nor disturb the butterflies / MFMA batches."""
+    cfg, robot, p, names, o, d = pair("anymal_c_flat", N)
+    init_both(o, d, N)
+    g = torch.Generator().manual_seed(N)
+    for it in (1, 2, 3):
+        act = (torch.randn(N, 12, generator=g) * 0.4).float()
+        o.step(act.numpy(), it); d.step(act.cuda(), it)
+    q_o, q_d = o.buf["dof_state"].reshape(N, 12, 2), get(d, "dof_state").reshape(N, 12, 2)
+    assert np.abs(q_o[..., 0] - q_d[..., 0]).max() < 5e-4 and np.abs(q_o[..., 1] - q_d[..., 1]).max() < 5e-2
+    assert maxdiff(o, d, "sea_hidden_state") < 5e-3 and maxdiff(o, d, "rew_buf") < 1e-3
+    assert np.array_equal(o.buf["episode_length_buf"], get(d, "episode_length_buf"))
+    assert np.isfinite(get(d, "obs_buf")).all()
