@@ -118,6 +118,19 @@ LG_DEV void contact_evaluate(Contact &c, const lg_params &P, float kn, float mu,
     }
 }
 
+// torque a drive still delivers at joint speed qd (fades out over the last 10 % below the velocity limit when driving
+// the joint faster): keeps saturated controllers from pumping momentum through the post-integration velocity clamp
+LG_DEV float motor_torque(float tau, float qd, float vlim) {
+    if (vlim <= 0.0f || tau * qd <= 0.0f) return tau;
+    float s = (vlim - fabsf(qd)) / (0.1f * vlim);
+    return tau * fminf(fmaxf(s, 0.0f), 1.0f);
+}
+LG_DEV V3 clamp_norm(V3 a, float lim) {           // asset.max_linear/angular_velocity guard; maps inf/NaN to 0
+    float n2 = dot(a, a);
+    if (!(n2 <= lim * lim)) { float k = (n2 > 0.0f && n2 < INFINITY) ? lim * __builtin_amdgcn_rsqf(n2) : 0.0f; return a * k; }
+    return a;
+}
+
 template <class T, bool HF>
 LG_DEV void physics_substep(const KArgs &A, const float *tab, int lane_k, float (&root)[13], float (&q)[T::L], float (&qd)[T::L],
                             const float (&tau)[T::L], float base_mass, float mu,
@@ -227,7 +240,9 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, int lane_k, float 
 
     // ---- articulated-body passes with the contact impedances folded in
     S6 U[L], acc0;
-    float Dinv[L], uu[L];
+    float Dinv[L], uu[L], vl[L];      // vl: 0, or +-1 = joint speed limit active in that direction (set by the previous pass)
+#pragma unroll
+    for (int j = 0; j < L; j++) vl[j] = 0.0f;
 #pragma unroll 1
     for (int pass = 0; pass < LG_PASSES; pass++) {
         AI Ia; S6 pa;
@@ -241,7 +256,7 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, int lane_k, float 
             U[j] = ai_mul_w(IA, ax[j]);
             float damp = tj[J_DAMP];
             float D = dot(ax[j], U[j].w) + tj[J_ARM] + dt * damp;
-            float u = tau[j] - dot(ax[j], pA.w) - damp * qd[j];
+            float u = motor_torque(tau[j], qd[j], tj[J_VLIM]) - dot(ax[j], pA.w) - damp * qd[j];
             float lo = tj[J_LO], hi = tj[J_HI];
             if (lo <= hi) {
                 float qp = q[j] + dt * qd[j];
@@ -252,6 +267,11 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, int lane_k, float 
                     D += dt * kl;
                     u += -P.limit_stiffness * viol - kl * qd[j];
                 }
+            }
+            if (vl[j] != 0.0f) {      // implicit damper towards +-v_lim (100x the joint's articulated inertia), reaction on the parent
+                float Bv = 100.0f * D / dt;
+                u += -Bv * (qd[j] - vl[j] * tj[J_VLIM]);
+                D += dt * Bv;
             }
             Dinv[j] = __builtin_amdgcn_rcpf(D); uu[j] = u;
             Ia = IA;
@@ -278,6 +298,10 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, int lane_k, float 
             a.w = ap.w + ax[j] * qdd;
             a.v = ap.v;
             uu[j] = qdd;
+            {
+                float lim = tab[j * LG_JS + J_VLIM], qn = qd[j] + dt * qdd;
+                if (lim > 0.0f && vl[j] == 0.0f && fabsf(qn) > lim) vl[j] = qn > 0.0f ? 1.0f : -1.0f;
+            }
 #pragma unroll
             for (int i = 0; i < NPT; i++) if (T::pt_joint(i) == j) contact_evaluate(cl[i], P, kn, mu, a);
         }
@@ -294,7 +318,7 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, int lane_k, float 
     }
     {
         V3 a_lin = acc0.v + cross(w0, v0);
-        V3 w1 = w0 + acc0.w * dt, v1 = v0 + a_lin * dt;
+        V3 w1 = clamp_norm(w0 + acc0.w * dt, 1000.0f), v1 = clamp_norm(v0 + a_lin * dt, 1000.0f);
         root[7] = v1.x; root[8] = v1.y; root[9] = v1.z; root[10] = w1.x; root[11] = w1.y; root[12] = w1.z;
         root[0] += dt * v1.x; root[1] += dt * v1.y; root[2] += dt * v1.z;
         float x = root[3], y = root[4], z = root[5], w = root[6], hx = 0.5f * dt * w1.x, hy = 0.5f * dt * w1.y, hz = 0.5f * dt * w1.z;
@@ -655,7 +679,13 @@ __global__ void __launch_bounds__(LG_BLOCK) k_step(const KArgs A) {
     float coll = group_sum<K>(coll_local);
     if (A.penalised_mask & 1u) coll += (nbase > 0.1f) ? 1.0f : 0.0f;
     const bool time_out = ep_len > P.max_episode_length;
-    const bool reset = contact_term || time_out;
+    int bad = 0;                                    // safety net: a non-finite state ends the episode
+#pragma unroll
+    for (int i = 0; i < 13; i++) bad |= !isfinite(root[i]);
+#pragma unroll
+    for (int j = 0; j < L; j++) bad |= !isfinite(q[j]) || !isfinite(qd[j]);
+    bad = group_or<K>(bad);
+    const bool reset = contact_term || time_out || bad;
 
     // compute_reward :193-210 ; terms :872-969, cassie.py:43-46
     float last_act[L];
@@ -823,7 +853,7 @@ __global__ void __launch_bounds__(LG_BLOCK) k_step(const KArgs A) {
     if (threadIdx.x == 0) {
         unsigned int ticket = atomicAdd(A.done_counter, 1u);
         s_last = (ticket == gridDim.x - 1);
-        if (s_last) *A.done_counter = 0u;          // nothing else touches it until the next launch on this stream
+        if (s_last) __hip_atomic_store(A.done_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // idle until the next launch
     }
     __syncthreads();
     if (s_last) finish_extras(A, threadIdx.x, step, true);

@@ -54,11 +54,21 @@ class LeggedRobot(BaseTask):
         self._obs_flip ^= 1
         self.obs_buf = self._obs_pair[self._obs_flip]
         self._sim.set_obs_output(self.obs_buf)
-        self._sim.step(actions, self.common_step_counter)
+        # while a caller captures a multi-step HIP graph (rl/runner.py) the counter must come from the device
+        self._sim.step(actions, -1 if self._capturing else self.common_step_counter)
         return self.obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf, self.extras
 
     def post_physics_step(self):
         raise RuntimeError("post_physics_step is fused into lg_step; call step()")
+
+    def begin_graph_capture(self):
+        """Prepare for capturing several step() calls into one HIP graph: the step counter moves to the device."""
+        self._sim.buf["step_counter"].fill_(self.common_step_counter)
+        self._capturing = True
+
+    def end_graph_capture(self, steps_captured: int):
+        self._capturing = False
+        self.common_step_counter -= steps_captured      # capture does not execute; replays are accounted by the caller
 
     def make_graphed_step(self, policy_act, warmup=3):
         """Capture ``actions = policy_act(obs_buf); step(actions)`` into one HIP graph and return a
@@ -261,6 +271,7 @@ class LeggedRobot(BaseTask):
         self.obs_buf, self.rew_buf = b["obs_buf"], b["rew_buf"]
         self._obs_pair = (b["obs_buf"], torch.zeros_like(b["obs_buf"]))
         self._obs_flip = 0
+        self._capturing = False
         self.reset_buf, self.time_out_buf = b["reset_buf"], b["time_out_buf"]
         self.reset_buf.fill_(True)                                   # base_task.py:73 starts at ones
         self.episode_length_buf = b["episode_length_buf"]

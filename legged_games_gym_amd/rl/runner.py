@@ -28,6 +28,62 @@ class OnPolicyRunner:
         self.tot_timesteps, self.tot_time, self.current_learning_iteration = 0, 0.0, 0
         _, _ = self.env.reset()
 
+    # ------------------------------------------------------------------ graphed rollout
+    def _rollout_steps(self, stats):
+        """num_steps_per_env x (act -> env.step -> store); episode statistics as tensor ops (no host sync)."""
+        env, alg = self.env, self.alg
+        obs = env.get_observations()
+        pobs = env.get_privileged_observations()
+        cobs = pobs if pobs is not None else obs
+        for _ in range(self.num_steps_per_env):
+            actions = alg.act(obs, cobs)
+            obs, pobs, rewards, dones, infos = env.step(actions)
+            cobs = pobs if pobs is not None else obs
+            alg.process_env_step(rewards, dones, infos)
+            d = dones.float()
+            stats["cur_rew"] += rewards
+            stats["cur_len"] += 1.0
+            stats["sum_rew"] += (stats["cur_rew"] * d).sum()
+            stats["sum_len"] += (stats["cur_len"] * d).sum()
+            stats["count"] += d.sum()
+            stats["cur_rew"] *= 1.0 - d
+            stats["cur_len"] *= 1.0 - d
+        return obs, cobs
+
+    def _try_build_graphed_rollout(self):
+        """Capture the whole rollout of one PPO iteration into a single HIP graph (one hipGraphLaunch per iteration
+        instead of ~24 x 30 eager launches).  Needs this package's env (device step counter, ping-pong obs buffers)
+        and an even number of steps so the observation buffers line up between replays."""
+        env = self.env
+        ok = (str(self.device).startswith("cuda") and hasattr(env, "begin_graph_capture") and self.num_steps_per_env % 2 == 0
+              and self.cfg.get("graphed_rollout", True))
+        if not ok:
+            return None
+        try:
+            N, dev = env.num_envs, self.device
+            stats = {k: torch.zeros(N if k.startswith("cur") else (), device=dev) for k in ("cur_rew", "cur_len", "sum_rew", "sum_len", "count")}
+            with torch.inference_mode():
+                self._rollout_steps(stats)              # one eager warm-up rollout (allocators, lazy init); discarded
+                self.alg.storage.clear()
+                for v in stats.values():
+                    v.zero_()
+                torch.cuda.synchronize()
+                flip0, counter0 = env._obs_flip, env.common_step_counter
+                env.begin_graph_capture()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    obs, cobs = self._rollout_steps(stats)
+                env.end_graph_capture(self.num_steps_per_env)
+                assert env._obs_flip == flip0 and env.common_step_counter == counter0
+            self.alg.storage.clear()
+            return graph, stats, obs, cobs
+        except Exception as exc:                          # fall back to eager launches
+            print(f"[runner] graphed rollout unavailable ({type(exc).__name__}: {exc}); using eager steps")
+            if hasattr(env, "_capturing"):
+                env._capturing = False
+            self.alg.storage.clear()
+            return None
+
     def learn(self, num_learning_iterations, init_at_random_ep_len=False):
         if init_at_random_ep_len:
             self.env.episode_length_buf[:] = torch.randint_like(self.env.episode_length_buf, high=int(self.env.max_episode_length))
@@ -39,26 +95,42 @@ class OnPolicyRunner:
         rewbuffer, lenbuffer = deque(maxlen=100), deque(maxlen=100)
         cur_rew = torch.zeros(self.env.num_envs, dtype=torch.float, device=self.device)
         cur_len = torch.zeros(self.env.num_envs, dtype=torch.float, device=self.device)
+        graphed = self._try_build_graphed_rollout()
         last = self.current_learning_iteration + num_learning_iterations
         for it in range(self.current_learning_iteration, last):
             t0 = time.time()
-            with torch.inference_mode():
-                for _ in range(self.num_steps_per_env):
-                    actions = self.alg.act(obs, cobs)
-                    obs, pobs, rewards, dones, infos = self.env.step(actions)
-                    cobs = pobs if pobs is not None else obs
-                    obs, cobs, rewards, dones = obs.to(self.device), cobs.to(self.device), rewards.to(self.device), dones.to(self.device)
-                    self.alg.process_env_step(rewards, dones, infos)
+            if graphed is not None:
+                graph, stats, obs, cobs = graphed
+                with torch.inference_mode():
+                    graph.replay()
+                    self.env.common_step_counter += self.num_steps_per_env
+                    self.alg.storage.step = self.num_steps_per_env
                     if self.log_dir is not None:
-                        cur_rew += rewards
-                        cur_len += 1
-                        ids = (dones > 0).nonzero(as_tuple=False)
-                        rewbuffer.extend(cur_rew[ids][:, 0].cpu().numpy().tolist())
-                        lenbuffer.extend(cur_len[ids][:, 0].cpu().numpy().tolist())
-                        cur_rew[ids] = 0
-                        cur_len[ids] = 0
-                t1 = time.time()
-                self.alg.compute_returns(cobs)
+                        s_rew, s_len, cnt = (float(v) for v in torch.stack((stats["sum_rew"], stats["sum_len"], stats["count"])).cpu())
+                        if cnt > 0:
+                            rewbuffer.append(s_rew / cnt); lenbuffer.append(s_len / cnt)
+                        for k in ("sum_rew", "sum_len", "count"):
+                            stats[k].zero_()
+                    t1 = time.time()
+                    self.alg.compute_returns(cobs)
+            else:
+                with torch.inference_mode():
+                    for _ in range(self.num_steps_per_env):
+                        actions = self.alg.act(obs, cobs)
+                        obs, pobs, rewards, dones, infos = self.env.step(actions)
+                        cobs = pobs if pobs is not None else obs
+                        obs, cobs, rewards, dones = obs.to(self.device), cobs.to(self.device), rewards.to(self.device), dones.to(self.device)
+                        self.alg.process_env_step(rewards, dones, infos)
+                        if self.log_dir is not None:
+                            cur_rew += rewards
+                            cur_len += 1
+                            ids = (dones > 0).nonzero(as_tuple=False)
+                            rewbuffer.extend(cur_rew[ids][:, 0].cpu().numpy().tolist())
+                            lenbuffer.extend(cur_len[ids][:, 0].cpu().numpy().tolist())
+                            cur_rew[ids] = 0
+                            cur_len[ids] = 0
+                    t1 = time.time()
+                    self.alg.compute_returns(cobs)
             mean_value_loss, mean_surrogate_loss = self.alg.update()
             t2 = time.time()
             self.tot_timesteps += self.num_steps_per_env * self.env.num_envs

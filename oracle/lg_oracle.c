@@ -257,6 +257,24 @@ static void ground_query(const lgo_sim *s, float x, float y, float *h, v3 *n) {
     *n = V(-dhdx * l, -dhdy * l, l);
 }
 
+/* Torque a drive can still deliver at joint speed qd: fades linearly to zero over the last 10 % below the URDF velocity
+ * limit when it would accelerate the joint further (no-load speed of the motor).  Without it a saturated controller on a
+ * light link relies on the post-integration velocity clamp, which removes the link's momentum while the base keeps the
+ * reaction: a momentum pump (observed: Cassie's pelvis spun up to 180 rad/s).  The clamp stays as a last-resort guard. */
+#define LG_VEL_LIMIT_GAIN       100.0f
+#define LG_MAX_LINEAR_VELOCITY  1000.0f     /* asset.max_linear_velocity  (legged_robot_config.py:117) */
+#define LG_MAX_ANGULAR_VELOCITY 1000.0f     /* asset.max_angular_velocity (legged_robot_config.py:116) */
+static inline v3 clamp_norm(v3 a, float lim) {
+    float n2 = dot(a, a);
+    if (!(n2 <= lim * lim)) { float k = (n2 > 0.0f && n2 < INFINITY) ? lim / sqrtf(n2) : 0.0f; return scl(a, k); }   /* also maps inf/NaN to 0 */
+    return a;
+}
+static inline float motor_torque(float tau, float qd, float vlim) {
+    if (vlim <= 0.0f || tau * qd <= 0.0f) return tau;
+    float s = (vlim - fabsf(qd)) / (0.1f * vlim);
+    return tau * fminf(fmaxf(s, 0.0f), 1.0f);
+}
+
 /* ------------------------------------------------------------------ physics sub-step (stands in for legged_robot.py:92-96) */
 #define NB (1 + LG_MAX_DOF)
 #define NPTS (LG_MAX_BASE_POINTS + LG_MAX_LIMBS * LG_MAX_LIMB_POINTS)
@@ -402,6 +420,8 @@ static void physics_substep_env(const lgo_sim *s, int e, const float *tau, int w
     /* ---- articulated-body passes with implicit contact impedances */
     sv6 U[NB], acc[NB];
     float Dinv[NB], uu[NB];
+    float vl[NB];                      /* 0, or +-1: joint speed limit active in that direction (set by the previous pass) */
+    for (int b = 0; b <= nd; b++) vl[b] = 0.0f;
     for (int pass = 0; pass < LG_CONTACT_PASSES; pass++) {
         ai6 IA[NB]; sv6 pA[NB];
         for (int b = 0; b <= nd; b++) { IA[b] = I0[b]; pA[b] = p0[b]; }
@@ -425,7 +445,7 @@ static void physics_substep_env(const lgo_sim *s, int e, const float *tau, int w
             sv6 Sb = {ax[b], V(0, 0, 0)};
             U[b] = ai_mul(&IA[b], Sb);
             float D = dot(ax[b], U[b].w) + M->dof_armature[d] + dt * M->dof_damping[d];
-            float u = tau[d] - dot(ax[b], pA[b].w) - M->dof_damping[d] * qd;
+            float u = motor_torque(tau[d], qd, M->dof_vel_limit[d]) - dot(ax[b], pA[b].w) - M->dof_damping[d] * qd;
             if (M->dof_lower[d] <= M->dof_upper[d]) {       /* implicit joint-limit spring-damper */
                 /* active when the explicit prediction leaves [lower, upper]:
                  * tau_l = -k (q' - lim) - b qd'  with q' = q + dt qd', qd' = qd + dt qdd */
@@ -437,6 +457,13 @@ static void physics_substep_env(const lgo_sim *s, int e, const float *tau, int w
                     D += dt * kl;
                     u += -P->limit_stiffness * viol - kl * qd;
                 }
+            }
+            if (vl[b] != 0.0f) {
+                /* joint speed limit as an implicit damper towards +-v_lim, 100x the joint's own articulated inertia:
+                 * pins qd' to the limit with the reaction carried by the parent (momentum-conserving, unlike a clamp) */
+                float Bv = LG_VEL_LIMIT_GAIN * D / dt;
+                u += -Bv * (qd - vl[b] * M->dof_vel_limit[d]);
+                D += dt * Bv;
             }
             Dinv[b] = 1.0f / D; uu[b] = u;
             /* Ia = IA - U U^T / D ; pa = pA + Ia c + U u / D ; shift to the parent's origin ; accumulate */
@@ -469,6 +496,11 @@ static void physics_substep_env(const lgo_sim *s, int e, const float *tau, int w
             acc[b].w = add(ap.w, scl(ax[b], qdd));
             acc[b].v = ap.v;
             uu[b] = qdd;                 /* reuse: joint acceleration */
+            {
+                int d = b - 1;
+                float lim = M->dof_vel_limit[d], qn = dof[2 * d + 1] + dt * qdd;
+                if (lim > 0.0f && vl[b] == 0.0f && fabsf(qn) > lim) vl[b] = qn > 0.0f ? 1.0f : -1.0f;
+            }
         }
         /* evaluate contacts at the end-of-step velocity and (re)classify */
         for (int i = 0; i < nc; i++) if (ct[i].on) {
@@ -494,6 +526,7 @@ static void physics_substep_env(const lgo_sim *s, int e, const float *tau, int w
     v3 w0 = wb[0], v0 = vb[0];
     v3 a_lin = add(acc[0].v, cross(w0, v0));          /* classical acceleration of the base origin */
     v3 w1 = add(w0, scl(acc[0].w, dt)), v1 = add(v0, scl(a_lin, dt));
+    w1 = clamp_norm(w1, LG_MAX_ANGULAR_VELOCITY); v1 = clamp_norm(v1, LG_MAX_LINEAR_VELOCITY);
     root[7] = v1.x; root[8] = v1.y; root[9] = v1.z; root[10] = w1.x; root[11] = w1.y; root[12] = w1.z;
     root[0] += dt * v1.x; root[1] += dt * v1.y; root[2] += dt * v1.z;
     {   /* q <- normalize(q + dt/2 * (w,0) (x) q) */
@@ -712,7 +745,10 @@ static void post_physics_env(const lgo_sim *s, int e, int64_t step) {
         if (n > 1.0f) contact_term = 1;
     }
     int time_out = s->B.episode_length_buf[e] > P->max_episode_length;
-    int reset = contact_term || time_out;
+    int finite = 1;                                  /* safety net: a non-finite state ends the episode (PhysX never emits NaN) */
+    for (int i = 0; i < 13; i++) finite &= isfinite(root[i]) ? 1 : 0;
+    for (int d = 0; d < 2 * nd; d++) finite &= isfinite(dof[d]) ? 1 : 0;
+    int reset = contact_term || time_out || !finite;
     s->B.time_out_buf[e] = (uint8_t)time_out;
     s->B.reset_buf[e] = (uint8_t)reset;
 

@@ -288,3 +288,29 @@ def test_tiny_and_ragged_env_counts(N):
     assert maxdiff(o, d, "sea_hidden_state") < 5e-3 and maxdiff(o, d, "rew_buf") < 1e-3
     assert np.array_equal(o.buf["episode_length_buf"], get(d, "episode_length_buf"))
     assert np.isfinite(get(d, "obs_buf")).all()
+
+
+def test_cassie_rough_soak_stays_finite():
+    """Regression for a GPU memory fault: Cassie on the height field under a random policy used to reach NaN states
+    (momentum pump through the joint-speed clamp).  1500 steps x 1024 envs, wild actions, everything must stay finite."""
+    N = 1024
+    terr = _rough_terrain(N)
+
+    def tweak(cfg):
+        cfg.terrain.mesh_type, cfg.terrain.num_rows, cfg.terrain.num_cols, cfg.terrain.border_size = "heightfield", 4, 5, 5
+    from legged_games_gym_amd.device_sim import DeviceSim
+    cfg, robot, p, names, model, w = make_setup("cassie", N, tweak=tweak, terrain=terr, plane=False)
+    d = DeviceSim(p, model, robot, torch.device("cuda:0"), w, terr.heightsamples, terr.env_origins)
+    lv = torch.randint(0, 4, (N,), dtype=torch.int32); ty = (torch.arange(N) * 5 // N).to(torch.int32)
+    d.buf["terrain_levels"].copy_(lv); d.buf["terrain_types"].copy_(ty)
+    d.buf["env_origins"].copy_(torch.from_numpy(terr.env_origins[lv.numpy(), ty.numpy()].astype(np.float32)))
+    d.reset_idx(torch.arange(N, dtype=torch.int32), 0)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    wmax = 0.0
+    for it in range(1, 1501):
+        d.step(torch.randn(N, 12, device="cuda", generator=g) * 2.0, it)
+        if it % 100 == 0:
+            r = get(d, "root_states")
+            assert np.isfinite(r).all() and np.isfinite(get(d, "obs_buf")).all()
+            wmax = max(wmax, float(np.abs(r[:, 10:13]).max()))
+    assert wmax < 80.0, wmax

@@ -175,3 +175,29 @@ def test_deterministic_and_thread_independent(oracle_lib):
         assert np.array_equal(a, b)
     for a, b in zip(outs[0], outs[2]):
         assert np.array_equal(a, b)
+
+
+def test_saturated_actuators_do_not_pump_momentum(oracle_lib):
+    """Regression: wild actions saturate Cassie's PD torques (195 N m on a 0.15 kg toe).  A post-integration joint-speed
+    clamp alone deletes link momentum while the base keeps the reaction and spun the pelvis to 180 rad/s -> NaN.
+    With the motor torque fading at the speed limit and the limit enforced inside the ABA the robot just tumbles."""
+    N = 128
+    cfg, robot, p, o = sim("cassie", N, threads=4)
+    o.reset_idx(np.arange(N, dtype=np.int32), 0)
+    rng = np.random.default_rng(0)
+    wmax = 0.0
+    for it in range(1, 601):
+        o.step((rng.standard_normal((N, 12)) * 2.0).astype(np.float32), it)
+        assert np.isfinite(o.buf["root_states"]).all() and np.isfinite(o.buf["dof_state"]).all()
+        wmax = max(wmax, np.abs(o.buf["root_states"][:, 10:13]).max())
+    assert wmax < 60.0, wmax
+    assert np.abs(o.dof_vel).max() <= robot.dof_velocity.max() * 1.001
+
+
+def test_non_finite_state_forces_a_reset(oracle_lib):
+    cfg, robot, p, o = sim("anymal_c_flat", 4)
+    o.reset_idx(np.arange(4, dtype=np.int32), 0)
+    o.step(np.zeros((4, 12), np.float32), 1)
+    o.buf["root_states"][2, 8] = np.nan
+    o.step(np.zeros((4, 12), np.float32), 2)
+    assert o.buf["reset_buf"].tolist() == [0, 0, 1, 0] and np.isfinite(o.buf["root_states"]).all() and np.isfinite(o.buf["obs_buf"]).all()
