@@ -25,14 +25,14 @@ using namespace lg;
 #define LG_PASSES 2
 
 // ------------------------------------------------------------------ robot topologies compiled in
-struct AnymalTraits {          // base + 4 legs x (HAA,HFE,KFE); points: thigh capsule, shank capsule, foot sphere
-    static constexpr int K = 4, L = 3, NBASE = 2, NREP = 4, NPT = 5;
+struct AnymalTraits {          // quadruped (ANYmal-C/B, A1): base + 4 legs x 3 joints; points: 2 thigh, 2 shank, foot sphere
+    static constexpr int K = 4, L = 3, NREP = 4, NPT = 5;
     static constexpr int pt_joint(int i) { return i < 2 ? 1 : 2; }
     static constexpr int pt_rep(int i) { return i < 2 ? 1 : (i < 4 ? 2 : 3); }
     static constexpr int FOOT_REP = 3;
 };
 struct CassieTraits {          // pelvis + 2 legs x 6 joints; points: toe capsule
-    static constexpr int K = 2, L = 6, NBASE = 1, NREP = 6, NPT = 2;
+    static constexpr int K = 2, L = 6, NREP = 6, NPT = 2;
     static constexpr int pt_joint(int) { return 5; }
     static constexpr int pt_rep(int) { return 5; }
     static constexpr int FOOT_REP = 5;
@@ -42,7 +42,7 @@ template <class T> struct Tab { static constexpr int STRIDE = T::L * LG_JS + 4 *
 enum { J_POS = 0, J_ROT = 3, J_AXIS = 12, J_MASS = 15, J_COM = 16, J_INERTIA = 19, J_LO = 25, J_HI = 26, J_VLIM = 27,
        J_ARM = 28, J_DAMP = 29, J_KP = 30, J_KD = 31, J_Q0 = 32, J_TLIM = 33, J_SLO = 34, J_SHI = 35, J_DVL = 36 };
 
-struct BaseTab { float mass, com[3], inertia[6]; float pts[LG_MAX_BASE_POINTS][4]; };
+struct BaseTab { float mass, com[3], inertia[6]; float pts[LG_MAX_BASE_POINTS][4]; int32_t num_pts; };   // num_pts <= K
 
 struct KArgs {                 // passed by value: lives in the kernarg segment -> scalar loads
     lg_params  P;
@@ -135,7 +135,7 @@ template <class T, bool HF>
 LG_DEV void physics_substep(const KArgs &A, const float *tab, int lane_k, float (&root)[13], float (&q)[T::L], float (&qd)[T::L],
                             const float (&tau)[T::L], float base_mass, float mu,
                             float (&Frep)[T::NREP][3], float (&Fbase)[3]) {
-    constexpr int K = T::K, L = T::L, NPT = T::NPT, NBASE = T::NBASE;
+    constexpr int K = T::K, L = T::L, NPT = T::NPT;
     const lg_params &P = A.P;
     const float dt = P.sim_dt;
     const V3 grav = v3(P.gravity[0], P.gravity[1], P.gravity[2]);
@@ -182,16 +182,16 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, int lane_k, float 
         body_terms(base_mass, v3(A.base.com[0], A.base.com[1], A.base.com[2]), Il, R0, w0, v0, I0b, p0b);
         // base collision points are split over the env's lanes (lane i owns point i); their inertia / bias contribution
         // joins the lane's limb contribution before the butterfly, their force is butterfly-summed afterwards
-        static_assert(NBASE <= K, "one base point per lane at most");
+        static_assert(K <= LG_MAX_BASE_POINTS, "one base point per lane at most");
         {
             float bp[4] = {A.base.pts[0][0], A.base.pts[0][1], A.base.pts[0][2], A.base.pts[0][3]};
 #pragma unroll
-            for (int i = 1; i < NBASE; i++) if (lane_k == i) { bp[0] = A.base.pts[i][0]; bp[1] = A.base.pts[i][1]; bp[2] = A.base.pts[i][2]; bp[3] = A.base.pts[i][3]; }
+            for (int i = 1; i < K; i++) if (lane_k == i) { bp[0] = A.base.pts[i][0]; bp[1] = A.base.pts[i][1]; bp[2] = A.base.pts[i][2]; bp[3] = A.base.pts[i][3]; }
             V3 r = mul(R0, v3(bp[0], bp[1], bp[2]));
             float h; V3 n;
             ground_query<HF>(A, root[0] + r.x, root[1] + r.y, h, n);
             contact_setup(cb, P, mu, r, n, bp[3] - (root[2] + r.z - h) * n.z, v0 + cross(w0, r), v3(Fbase[0], Fbase[1], Fbase[2]));
-            cb.on = cb.on && (lane_k < NBASE);
+            cb.on = cb.on && (lane_k < A.base.num_pts);
         }
     }
     {
@@ -1053,7 +1053,7 @@ struct lg_sim {
 
 template <class T> static int check_topology(const lg_robot_model *m) {
     if (m->num_limbs != T::K || m->chain_len != T::L) return 0;
-    if (m->num_bodies != 1 + T::K * T::NREP || m->num_base_points != T::NBASE) return 0;
+    if (m->num_bodies != 1 + T::K * T::NREP || m->num_base_points < 1 || m->num_base_points > T::K) return 0;
     for (int i = 0; i < m->num_base_points; i++) if (m->base_points[i].report_body != 0) return 0;
     for (int k = 0; k < T::K; k++) {
         if (m->num_limb_points[k] != T::NPT) return 0;
@@ -1117,6 +1117,7 @@ static int upload_tables(lg_sim *s) {
     s->base.mass = s->M.base_mass;
     memcpy(s->base.com, s->M.base_com, 12); memcpy(s->base.inertia, s->M.base_inertia, 24);
     memset(s->base.pts, 0, sizeof s->base.pts);
+    s->base.num_pts = s->M.num_base_points;
     for (int i = 0; i < s->M.num_base_points; i++) { memcpy(s->base.pts[i], s->M.base_points[i].pos, 12); s->base.pts[i][3] = s->M.base_points[i].radius; }
     return 0;
 }

@@ -334,6 +334,74 @@ class AnymalCFlatCfgPPO(AnymalCRoughCfgPPO):
 
 
 # --------------------------------------------------------------------------- #
+#  ANYmal-B (anymal_b_config.py:33-45) and Unitree A1 (a1_config.py:33-86)
+# --------------------------------------------------------------------------- #
+class AnymalBRoughCfg(AnymalCRoughCfg):
+    class asset(AnymalCRoughCfg.asset):
+        file = _ROOT + "/resources/robots/anymal_b/urdf/anymal_b.urdf"
+        foot_name = "FOOT"
+        name = "anymal_b"
+
+    class rewards(AnymalCRoughCfg.rewards):
+        class scales(AnymalCRoughCfg.rewards.scales):
+            pass
+
+
+class AnymalBRoughCfgPPO(AnymalCRoughCfgPPO):
+    class runner(AnymalCRoughCfgPPO.runner):
+        experiment_name = "rough_anymal_b"
+        load_run = -1
+        run_name = ""
+
+
+def _a1_default_angles():
+    q = {}
+    for leg in ("FL", "RL", "FR", "RR"):
+        q[f"{leg}_hip_joint"] = 0.1 if leg[1] == "L" else -0.1
+        q[f"{leg}_thigh_joint"] = 0.8 if leg[0] == "F" else 1.0
+        q[f"{leg}_calf_joint"] = -1.5
+    return q
+
+
+class A1RoughCfg(LeggedRobotCfg):
+    class asset(LeggedRobotCfg.asset):
+        file = _ROOT + "/resources/robots/a1/urdf/a1.urdf"
+        foot_name = "foot"
+        name = "a1"
+        penalize_contacts_on = ["thigh", "calf"]
+        self_collisions = 1
+        terminate_after_contacts_on = ["base"]
+
+    class control(LeggedRobotCfg.control):
+        action_scale = 0.25
+        control_type = "P"
+        damping = {"joint": 0.5}
+        decimation = 4
+        stiffness = {"joint": 20.0}
+
+    class init_state(LeggedRobotCfg.init_state):
+        default_joint_angles = _a1_default_angles()
+        pos = [0.0, 0.0, 0.42]
+
+    class rewards(LeggedRobotCfg.rewards):
+        base_height_target = 0.25
+        soft_dof_pos_limit = 0.9
+
+        class scales(LeggedRobotCfg.rewards.scales):
+            dof_pos_limits = -10.0
+            torques = -0.0002
+
+
+class A1RoughCfgPPO(LeggedRobotCfgPPO):
+    class algorithm(LeggedRobotCfgPPO.algorithm):
+        entropy_coef = 0.01
+
+    class runner(LeggedRobotCfgPPO.runner):
+        experiment_name = "rough_a1"
+        run_name = ""
+
+
+# --------------------------------------------------------------------------- #
 #  Cassie (cassie_config.py:33-112)
 # --------------------------------------------------------------------------- #
 def _cassie_default_angles():

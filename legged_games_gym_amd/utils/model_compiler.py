@@ -176,6 +176,31 @@ def _merge_inertial(parts):
     return m, com, I
 
 
+def _box_points(size, R, p, rep, sid):
+    """Sphere-swept stand-in for a box (the contact model works on spheres).  A rod-like box (one side >= 2.5x the others,
+    e.g. the A1 thigh 0.2 x 0.0245 x 0.034) becomes a capsule: two end spheres on the long axis with the mean half-thickness
+    as radius.  Any other box (robot trunks) becomes a rounded slab: four spheres of radius = half the smallest side at the
+    inset corners of the two larger sides.  Both touch the ground plane exactly where the box faces would."""
+    size = np.asarray(size, dtype=np.float64)
+    order = np.argsort(size)            # small, mid, large
+    sm, md, lg = size[order]
+    pts = []
+    if lg >= 2.5 * md:
+        rad = 0.25 * (sm + md)
+        h = max(0.5 * lg - rad, 0.0)
+        ax = R[:, order[2]]
+        for sgn in (1.0, -1.0):
+            pts.append(CollisionPoint(p + sgn * h * ax, rad, rep, sid))
+    else:
+        rad = 0.5 * sm
+        a1, a2 = R[:, order[2]], R[:, order[1]]
+        h1, h2 = max(0.5 * lg - rad, 0.0), max(0.5 * md - rad, 0.0)
+        for s1 in (1.0, -1.0):
+            for s2 in (1.0, -1.0):
+                pts.append(CollisionPoint(p + s1 * h1 * a1 + s2 * h2 * a2, rad, rep, sid))
+    return pts
+
+
 @dataclass
 class CollisionPoint:
     """A sphere of ``radius`` at ``pos`` (dynamic-body frame).  A capsule is two."""
@@ -411,6 +436,8 @@ def compile_urdf(path: str, collapse_fixed_joints=True, replace_cylinder_with_ca
                 ax = R[:, 2]
                 pts.append(CollisionPoint(p + h * ax, s.radius, rep, sid))
                 pts.append(CollisionPoint(p - h * ax, s.radius, rep, sid))
+            elif kind == "box":
+                pts.extend(_box_points(s.size, R, p, rep, sid))
             else:
                 raise ValueError(f"collision primitive {kind!r} is not supported on this path")
         return pts

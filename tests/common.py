@@ -15,7 +15,7 @@ from legged_games_gym_amd.utils import packing  # noqa: E402
 from legged_games_gym_amd.utils.model_compiler import load_model  # noqa: E402
 
 TASK_CFG = {"anymal_c_flat": configs.AnymalCFlatCfg, "anymal_c_rough": configs.AnymalCRoughCfg,
-            "cassie": configs.CassieRoughCfg}
+            "cassie": configs.CassieRoughCfg, "a1": configs.A1RoughCfg, "anymal_b": configs.AnymalBRoughCfg}
 
 
 def make_setup(task="anymal_c_flat", num_envs=64, seed=1, plane=None, terrain=None, tweak=None):

@@ -14,6 +14,8 @@ from legged_games_gym_amd.utils.helpers import class_to_dict
 PAIRS = {"anymal_c_rough": (configs.AnymalCRoughCfg, configs.AnymalCRoughCfgPPO),
          "anymal_c_flat": (configs.AnymalCFlatCfg, configs.AnymalCFlatCfgPPO),
          "cassie": (configs.CassieRoughCfg, configs.CassieRoughCfgPPO),
+         "a1": (configs.A1RoughCfg, configs.A1RoughCfgPPO),
+         "anymal_b": (configs.AnymalBRoughCfg, configs.AnymalBRoughCfgPPO),
          "base": (configs.LeggedRobotCfg, configs.LeggedRobotCfgPPO)}
 
 

@@ -42,7 +42,7 @@ def test_registry_errors_and_cassie_rough_creation():
     from legged_games_gym_amd.envs import task_registry
     from legged_games_gym_amd.utils import get_args
     with pytest.raises(ValueError, match="not registered"):
-        task_registry.make_env("a1", get_args(["--headless"]))
+        task_registry.make_env("high_level_game", get_args(["--headless"]))
     with pytest.raises(ValueError):
         task_registry.make_alg_runner(env=None, name=None, args=get_args(["--headless"]))
     env, cfg = _env("cassie", 32)                   # heightfield terrain + curriculum + height sampling + PD control
@@ -53,6 +53,25 @@ def test_registry_errors_and_cassie_rough_creation():
         obs, _, rew, dones, infos = env.step(torch.zeros(32, 12, device="cuda"))
     assert torch.isfinite(obs).all() and "terrain_level" in infos["episode"]
     assert obs.shape == (32, 169) and float(obs[:, 48:].abs().max()) <= 5.0 + 0.6
+
+
+@pytest.mark.parametrize("task,height", [("a1", 0.26), ("anymal_b", 0.47)])
+def test_a1_and_anymal_b_tasks_stand_on_rough_terrain(task, height):
+    """The two remaining locomotion tasks of the reference registry (envs/__init__.py): A1 (PD control, box shapes)
+    and ANYmal-B (actuator net); zero actions -> the robots stay up on the curriculum terrain's easy rows."""
+    env, cfg = _env(task, 64)
+    assert env.num_obs == 235 and env.num_actions == 12 and env.cfg.asset.name == task
+    env.reset()
+    z0 = torch.zeros(64, 12, device="cuda")
+    dones = 0
+    for _ in range(100):
+        obs, _, rew, d, infos = env.step(z0)
+        dones += int(d.sum())
+    assert torch.isfinite(obs).all() and torch.isfinite(rew).all()
+    rel_z = (env.root_states[:, 2] - env.measured_heights.mean(dim=1).clamp(-1, 1) * 0).cpu()
+    assert dones < 32                                             # a few fall on steeper tiles; most keep standing
+    assert float(env.contact_forces[:, env.feet_indices, 2].sum(dim=1).median()) > 0.5 * 9.81 * {"a1": 12.454, "anymal_b": 30.62}[task]
+    assert float((env.base_lin_vel.norm(dim=1) < 0.5).float().mean()) > 0.7 and rel_z.isfinite().all()
 
 
 def test_bundled_runner_learns_a_few_iterations(tmp_path):

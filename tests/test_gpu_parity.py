@@ -57,7 +57,7 @@ def init_both(o, d, N, seed=3, origins=None):
     d.reset_idx(torch.from_numpy(ids), 0)
 
 
-@pytest.mark.parametrize("task", ["anymal_c_flat", "cassie"])
+@pytest.mark.parametrize("task", ["anymal_c_flat", "cassie", "a1", "anymal_b"])
 def test_reset_is_bit_exact(task):
     N = 130                                       # not a multiple of the wave's env count: exercises the tail
     cfg, robot, p, names, o, d = pair(task, N)
@@ -74,7 +74,7 @@ def test_reset_is_bit_exact(task):
     assert np.array_equal(after[keep], before.reshape(N, 12, 2)[keep]) and maxdiff(o, d, "dof_state") == 0.0
 
 
-@pytest.mark.parametrize("task", ["anymal_c_flat", "cassie", "anymal_c_rough"])
+@pytest.mark.parametrize("task", ["anymal_c_flat", "cassie", "anymal_c_rough", "a1", "anymal_b"])
 def test_post_physics_block_parity(task):
     """decimation=0: termination, all reward terms, predicated reset, observations, bookkeeping -- no physics."""
     N = 300
@@ -126,7 +126,7 @@ def test_actuator_kernel_matches_golden_and_oracle(golden_dir):
     np.testing.assert_allclose(probe.cpu().numpy()[:4], g["survey_probe_first4"], atol=1e-4)
 
 
-@pytest.mark.parametrize("task", ["anymal_c_flat", "cassie"])
+@pytest.mark.parametrize("task", ["anymal_c_flat", "cassie", "a1", "anymal_b"])
 def test_physics_substep_parity(task):
     """One 5 ms rigid-body step from random states (airborne, touching and penetrating), given torques."""
     N = 512
@@ -134,7 +134,8 @@ def test_physics_substep_parity(task):
     init_both(o, d, N)
     rng = np.random.default_rng(2)
     root = o.buf["root_states"].copy()
-    root[:, 2] = rng.uniform(0.35, 0.75, N) if task != "cassie" else rng.uniform(0.7, 1.1, N)
+    lo, hi = {"cassie": (0.7, 1.1), "a1": (0.15, 0.45)}.get(task, (0.35, 0.75))
+    root[:, 2] = rng.uniform(lo, hi, N)
     quat = np.array([0, 0, 0, 1.0]) + rng.normal(0, 0.15, (N, 4)); quat /= np.linalg.norm(quat, axis=1, keepdims=True)
     root[:, 3:7] = quat
     root[:, 7:13] = rng.normal(0, 0.7, (N, 6))
@@ -162,11 +163,11 @@ def test_physics_substep_parity(task):
     assert np.abs(cf_o - cf_d).max() < 2e-4 * max(1.0, np.abs(cf_o).max()) + 0.5
     quiet = np.abs(cf_o).max(axis=(1, 2)) < 1e-9                           # airborne envs: pure ABA, fp32-level agreement
     # Cassie's 6-joint chains span three orders of magnitude of link inertia: looser fp32 agreement than the quadruped
-    rel = 2e-5 if task == "anymal_c_flat" else 2e-4
+    rel = 2e-4 if task == "cassie" else 2e-5
     assert quiet.sum() > 20 and (err_v[quiet] <= rel * (1.0 + dqd[quiet])).all()
 
 
-@pytest.mark.parametrize("task,plane", [("anymal_c_flat", True), ("cassie", True)])
+@pytest.mark.parametrize("task,plane", [("anymal_c_flat", True), ("cassie", True), ("a1", True), ("anymal_b", True)])
 def test_full_step_parity(task, plane):
     """One fused policy step (clip, 4 x (torque, physics), post-physics) and a short standing trajectory."""
     N = 256
@@ -181,7 +182,7 @@ def test_full_step_parity(task, plane):
     assert np.abs(o.buf["root_states"][:, :7] - get(d, "root_states")[:, :7]).max() < 1e-4
     assert maxdiff(o, d, "rew_buf") < 1e-4 and maxdiff(o, d, "obs_buf") < 2e-3
     assert np.array_equal(o.buf["reset_buf"], get(d, "reset_buf"))
-    if task == "anymal_c_flat":     # quadruped stands: 25 zero-action steps stay close (no contact switching)
+    if task != "cassie":            # quadrupeds stand: 25 zero-action steps stay close (no contact switching)
         z = torch.zeros(N, 12)
         for it in range(2, 27):
             o.step(z.numpy(), it); d.step(z.cuda(), it)

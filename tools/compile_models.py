@@ -31,7 +31,9 @@ OUT = os.path.join(REPO, "legged_games_gym_amd", "resources")
 
 def models():
     for stem, rel in (("anymal_c", "resources/robots/anymal_c/urdf/anymal_c.urdf"),
-                      ("cassie", "resources/robots/cassie/urdf/cassie.urdf")):
+                      ("cassie", "resources/robots/cassie/urdf/cassie.urdf"),
+                      ("anymal_b", "resources/robots/anymal_b/urdf/anymal_b.urdf"),
+                      ("a1", "resources/robots/a1/urdf/a1.urdf")):
         m = compile_urdf(os.path.join(REF, rel), name=stem)
         path = os.path.join(OUT, "models", stem + ".json")
         with open(path, "w") as fh:

@@ -64,9 +64,15 @@ def load_reference_configs():
     envs.AnymalCRoughCfg, envs.AnymalCRoughCfgPPO = rough.AnymalCRoughCfg, rough.AnymalCRoughCfgPPO
     flat = run("legged_gym.envs.anymal_c.flat.anymal_c_flat_config", "legged_gym/envs/anymal_c/flat/anymal_c_flat_config.py")
     cas = run("legged_gym.envs.cassie.cassie_config", "legged_gym/envs/cassie/cassie_config.py")
+    for pkg in ("legged_gym.envs.a1", "legged_gym.envs.anymal_b"):
+        mod(pkg).__path__ = []
+    a1 = run("legged_gym.envs.a1.a1_config", "legged_gym/envs/a1/a1_config.py")
+    anb = run("legged_gym.envs.anymal_b.anymal_b_config", "legged_gym/envs/anymal_b/anymal_b_config.py")
     return {"anymal_c_rough": (rough.AnymalCRoughCfg, rough.AnymalCRoughCfgPPO),
             "anymal_c_flat": (flat.AnymalCFlatCfg, flat.AnymalCFlatCfgPPO),
             "cassie": (cas.CassieRoughCfg, cas.CassieRoughCfgPPO),
+            "a1": (a1.A1RoughCfg, a1.A1RoughCfgPPO),
+            "anymal_b": (anb.AnymalBRoughCfg, anb.AnymalBRoughCfgPPO),
             "base": (lrc.LeggedRobotCfg, lrc.LeggedRobotCfgPPO)}
 
 
@@ -121,7 +127,9 @@ def g3():
     from legged_games_gym_amd.envs import configs
     out = {}
     for stem, rel, cfg in (("anymal_c", "resources/robots/anymal_c/urdf/anymal_c.urdf", configs.AnymalCRoughCfg),
-                           ("cassie", "resources/robots/cassie/urdf/cassie.urdf", configs.CassieRoughCfg)):
+                           ("cassie", "resources/robots/cassie/urdf/cassie.urdf", configs.CassieRoughCfg),
+                           ("anymal_b", "resources/robots/anymal_b/urdf/anymal_b.urdf", configs.AnymalBRoughCfg),
+                           ("a1", "resources/robots/a1/urdf/a1.urdf", configs.A1RoughCfg)):
         m = compile_urdf(os.path.join(REF, rel), name=stem)
         q0 = np.array([cfg.init_state.default_joint_angles[n] for n in m.dof_names])
         feet = m.bodies_matching(cfg.asset.foot_name)
