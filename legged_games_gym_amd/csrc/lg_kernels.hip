@@ -81,11 +81,11 @@ template <bool HF> LG_DEV void ground_query(const KArgs &A, float x, float y, fl
 }
 
 // ------------------------------------------------------------------ one 5 ms rigid-body step for (env, limb)
-struct Contact { V3 r, n, vc, f; float depth, bt, vtn; bool on; };
+struct Contact { V3 r, n, vc, f, fs; float depth, bt, vtn; bool on; };   // fs: constant sliding force of the corrector pass
 
 // fprev = previous sub-step's net contact force on the point's report body (seeds the friction secant)
 LG_DEV void contact_setup(Contact &c, const lg_params &P, float mu, V3 r, V3 n, float depth, V3 vc, V3 fprev) {
-    c.r = r; c.n = n; c.depth = depth; c.vc = vc; c.on = depth > -P.contact_margin; c.f = v3(0, 0, 0);
+    c.r = r; c.n = n; c.depth = depth; c.vc = vc; c.on = depth > -P.contact_margin; c.f = v3(0, 0, 0); c.fs = v3(0, 0, 0);
     float vn0 = dot(n, vc);
     V3 vt0 = vc - n * vn0;
     c.vtn = sqrtf(dot(vt0, vt0));
@@ -97,7 +97,7 @@ LG_DEV void contact_assemble(const Contact &c, const lg_params &P, float kn, AI 
         const float dt = P.sim_dt;
         float vn = dot(c.n, c.vc);
         V3 vt = c.vc - c.n * vn;
-        V3 f = c.n * (P.contact_stiffness * c.depth - kn * vn) - vt * c.bt;
+        V3 f = c.n * (P.contact_stiffness * c.depth - kn * vn) - vt * c.bt + c.fs;
         ai_add_point(IA, dt * c.bt, c.r);
         ai_add_rank1(IA, dt * (kn - c.bt), cross(c.r, c.n), c.n);
         pA.w = pA.w - cross(c.r, f);
@@ -112,8 +112,12 @@ LG_DEV void contact_evaluate(Contact &c, const lg_params &P, float kn, float mu,
         float fn = P.contact_stiffness * c.depth - kn * vn;
         if (fn <= 0.0f) { c.on = false; c.f = v3(0, 0, 0); }
         else {
-            c.f = c.n * fn - vt * c.bt;                                                      // force this pass applied
-            c.bt = fminf(P.friction_damping, mu * fn / fmaxf(c.vtn, P.stick_velocity));       // secant for the next pass
+            c.f = c.n * fn - vt * c.bt + c.fs;                                               // force this pass applied
+            // corrector for the next pass: beyond the cone -> slide with mu f_n against the predicted slip direction;
+            // inside it -> re-aim the secant at the predicted end-of-step slip speed (sticking points keep the stick impedance)
+            float vtm = sqrtf(dot(vt, vt)), cone = mu * fn;
+            if (c.bt * vtm > cone) { c.fs = vt * (-cone / vtm); c.bt = 0.0f; }
+            else if (c.bt > 0.0f) c.bt = fminf(P.friction_damping, cone / fmaxf(vtm, P.stick_velocity));
         }
     }
 }

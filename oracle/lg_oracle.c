@@ -287,6 +287,7 @@ typedef struct {
     float depth, kn, bt, mu, vtn;   /* vtn = tangential speed at the start of the step */
     int   on;
     v3    f;           /* resulting force (world) */
+    v3    fs;          /* constant sliding friction force of the corrector pass (zero while the damper form is used) */
 } contact_t;
 
 /* Re-express an articulated inertia / force given about point P at the point Q = P - d (d = P - Q):
@@ -413,6 +414,7 @@ static void physics_substep_env(const lgo_sim *s, int e, const float *tau, int w
                 c->bt = fminf(P->friction_damping, c->mu * fn_est / fmaxf(c->vtn, P->stick_velocity));
             }
             c->f = V(0, 0, 0);
+            c->fs = V(0, 0, 0);
             nc++;
         }
     }
@@ -431,7 +433,7 @@ static void physics_substep_env(const lgo_sim *s, int e, const float *tau, int w
             contact_t *c = &ct[i];
             float vn = dot(c->n, c->vc);
             v3 vt = sub(c->vc, scl(c->n, vn));
-            v3 f = sub(scl(c->n, P->contact_stiffness * c->depth - c->kn * vn), scl(vt, c->bt));
+            v3 f = add(sub(scl(c->n, P->contact_stiffness * c->depth - c->kn * vn), scl(vt, c->bt)), c->fs);
             ai6 *It = (c->body == 0) ? &IBp[i] : &IA[c->body];      /* base points are the first contacts: index i = point i */
             sv6 *pt_ = (c->body == 0) ? &pBp[i] : &pA[c->body];
             ai_add_point(It, dt * c->bt, c->r);
@@ -510,8 +512,13 @@ static void physics_substep_env(const lgo_sim *s, int e, const float *tau, int w
             v3 vt = sub(vn_, scl(c->n, vn));
             float fn = P->contact_stiffness * c->depth - c->kn * vn;
             if (fn <= 0.0f) { c->on = 0; c->f = V(0, 0, 0); continue; }
-            c->f = sub(scl(c->n, fn), scl(vt, c->bt));                           /* force this pass applied */
-            c->bt = fminf(P->friction_damping, c->mu * fn / fmaxf(c->vtn, P->stick_velocity));   /* secant for the next pass */
+            c->f = add(sub(scl(c->n, fn), scl(vt, c->bt)), c->fs);               /* force this pass applied */
+            /* corrector for the next pass: if the damper form needed more than the cone allows, the point slides -- apply
+             * mu f_n against the predicted slip direction as a constant force; otherwise re-aim the secant at the
+             * predicted end-of-step slip speed (never weaker than before: sticking points stay on the stick impedance). */
+            float vtm = sqrtf(dot(vt, vt)), cone = c->mu * fn;
+            if (c->bt * vtm > cone) { c->fs = scl(vt, -cone / vtm); c->bt = 0.0f; }
+            else if (c->bt > 0.0f) c->bt = fminf(P->friction_damping, cone / fmaxf(vtm, P->stick_velocity));
         }
     }
 

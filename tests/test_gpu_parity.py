@@ -163,7 +163,8 @@ def test_physics_substep_parity(task):
     assert np.abs(cf_o - cf_d).max() < 2e-4 * max(1.0, np.abs(cf_o).max()) + 0.5
     quiet = np.abs(cf_o).max(axis=(1, 2)) < 1e-9                           # airborne envs: pure ABA, fp32-level agreement
     # Cassie's 6-joint chains span three orders of magnitude of link inertia: looser fp32 agreement than the quadruped
-    rel = 2e-4 if task == "cassie" else 2e-5
+    # ... and 20 Nm of random torque on A1's 60 g feet / 170 g calves gives thousands of rad/s^2 (into the speed-limit band)
+    rel = {"cassie": 2e-4, "a1": 1e-4}.get(task, 2e-5)
     assert quiet.sum() > 20 and (err_v[quiet] <= rel * (1.0 + dqd[quiet])).all()
 
 

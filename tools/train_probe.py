@@ -9,12 +9,14 @@ iters = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 task = sys.argv[2] if len(sys.argv) > 2 else "anymal_c_flat"
 args = get_args(["--task", task, "--headless", "--sim_device", "cuda:0", "--rl_device", "cuda:0", "--max_iterations", str(iters)])
 env_cfg, train_cfg0 = task_registry.get_cfgs(task)
+if os.environ.get("LG_SEED"):            # the env seeds from the registered train cfg (reference quirk), not from --seed
+    train_cfg0.seed = int(os.environ["LG_SEED"])
 if os.environ.get("LG_UNCLIPPED"):
     env_cfg.rewards.only_positive_rewards = False
 if os.environ.get("LG_INIT_STD"):
     train_cfg0.policy.init_noise_std = float(os.environ["LG_INIT_STD"])
 env, env_cfg = task_registry.make_env(task, args, env_cfg=env_cfg)
-runner, train_cfg = task_registry.make_alg_runner(env, task, args, log_root="gpurun_out/train_logs")
+runner, train_cfg = task_registry.make_alg_runner(env, task, args, log_root=os.environ.get("LG_LOG_ROOT", "/tmp/lg_train_logs"))
 t0 = time.time()
 runner.learn(num_learning_iterations=iters, init_at_random_ep_len=True)
 print(f"total {time.time()-t0:.1f}s for {iters} iterations x 24 x {env.num_envs} = {iters*24*env.num_envs/1e6:.1f}M env-steps")
