@@ -188,7 +188,8 @@ _lib = None
 
 
 def library_path() -> str:
-    return os.path.join(os.path.dirname(os.path.realpath(__file__)), "csrc", _LIB_NAME)
+    """In-tree liblegged_hip.so; LG_HIP_LIB selects another build of the same sources (tools/profile_sections.py)."""
+    return os.environ.get("LG_HIP_LIB") or os.path.join(os.path.dirname(os.path.realpath(__file__)), "csrc", _LIB_NAME)
 
 
 def bind_prototypes(lib, prefix: str):

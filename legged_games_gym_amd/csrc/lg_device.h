@@ -260,6 +260,13 @@ LG_DEV void swap32(float &a, float &b) {        // a <- [a.lo | b.lo], b <- [a.h
 }
 LG_DEV float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.442695041f * x)); }
 LG_DEV float fast_tanh(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.885390082f * x)) - 1.0f; }
+// packed-fp32 pairs (v_pk_add/mul/fma_f32): two hidden units per instruction; exp2 / rcp stay per component
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define LSTM_EXP_CAP 0x1p30f   // sigma saturates at 9e-10 and a product of three (1 + e) terms stays far below FLT_MAX
+LG_DEV f32x2 exp2_capped(f32x2 a) {     // capped after the exp (2^x -> inf is fine as a min operand, and needs no input canonicalisation)
+    return f32x2{fminf(__builtin_amdgcn_exp2f(a.x), LSTM_EXP_CAP), fminf(__builtin_amdgcn_exp2f(a.y), LSTM_EXP_CAP)};
+}
+LG_DEV f32x2 rcp2(f32x2 a) { return f32x2{__builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y)}; }
 
 // per-lane 8-vector (u[0..7] of this lane's row) -> unit-split pair (g0[s], g1[s]); the same call inverts it
 LG_DEV void lstm_split(const float (&u)[8], float (&g0)[4], float (&g1)[4]) {
@@ -272,11 +279,25 @@ LG_DEV void lstm_unsplit(const float (&g0)[4], const float (&g1)[4], float (&u)[
 }
 struct LstmSplit { float h0[2][4], c0[2][4], h1[2][4], c1[2][4]; };      // [group][s]
 
+// LSTM cell on pre-activations that arrive PRE-SCALED by the weight table (build_lstm_table): rows i, f, o hold
+// -log2(e) x and rows g hold -2 log2(e) x, so sigma(x) = 1 / (1 + 2^a) and tanh(x) = (1 - 2^a) / (1 + 2^a) need no
+// multiply.  The five activations of a unit share two reciprocals (transcendentals are quarter rate):
+//   c' = sigma(f) c + sigma(i) tanh(g) = [c A G + (1 - e_g) F] / (F A G),   A = 1 + e_i, F = 1 + e_f, G = 1 + e_g
+//   h  = sigma(o) tanh(c')             = (1 - e_c) / (O C),                 O = 1 + e_o, C = 1 + e_c, e_c = 2^(-2 log2(e) c')
 LG_DEV void lstm_cell(const f32x16 &g, float (&h)[4], float (&c)[4]) {
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-        float cn = fast_sigmoid(g[4 + u]) * c[u] + fast_sigmoid(g[u]) * fast_tanh(g[8 + u]);
-        c[u] = cn; h[u] = fast_sigmoid(g[12 + u]) * fast_tanh(cn);
+    for (int u = 0; u < 4; u += 2) {
+        const f32x2 one = {1.0f, 1.0f}, two = {2.0f, 2.0f};
+        f32x2 A = one + exp2_capped(f32x2{g[u], g[u + 1]});
+        f32x2 F = one + exp2_capped(f32x2{g[4 + u], g[5 + u]});
+        f32x2 G = one + exp2_capped(f32x2{g[8 + u], g[9 + u]});
+        f32x2 O = one + exp2_capped(f32x2{g[12 + u], g[13 + u]});
+        f32x2 cc = {c[u], c[u + 1]};
+        f32x2 t = A * G;
+        f32x2 cn = (cc * t + (two - G) * F) * rcp2(F * t);
+        f32x2 C = one + exp2_capped(cn * -2.885390082f);
+        f32x2 hn = (two - C) * rcp2(O * C);
+        c[u] = cn.x; c[u + 1] = cn.y; h[u] = hn.x; h[u + 1] = hn.y;
     }
 }
 // One time step for the wave's 64 rows.  (pos_err, vel) are this lane's row; returns this lane's torque.
@@ -306,6 +327,71 @@ LG_DEV float actuator_step_mfma(const LstmLane &W, float pos_err, float vel, Lst
     }
     swap32(part[0], part[1]);                     // lanes < 32: (units 0-3, units 4-7) of group 0's row; lanes >= 32: group 1's
     return W.out_scale * ((part[0] + part[1]) + W.lb);
+}
+
+
+// All L joints of this lane for one sub-step: 2 L independent (joint, group) instances, fully unrolled so the bias
+// MFMAs (identical for every instance) are computed once and reused as the C operand.  `lds` is the parked unit-split
+// state: [joint * 8 + {h0,c0,h1,c1} * 2 + group][lane].  Measured on MI355X (tools/ubench/mfma_overlap.hip): a lone wave
+// does NOT overlap its own MFMA and VALU instructions (1 MFMA + 8 FMA = 49 ns vs 27 + 24 ns), so instance order is
+// irrelevant and the cost is simply 80 x 27 ns of matrix pipe + ~1200 vector instructions per sub-step.
+// Must be executed with all 64 lanes active.
+template <int L, int BLOCK>
+LG_DEV void actuator_substep_mfma(const LstmLane &W, float4 (*lds)[BLOCK], const float (&pos_err)[L], const float (&vel)[L], float (&tau)[L]) {
+    constexpr int NI = 2 * L;
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int lane = threadIdx.x;
+    float xg[L][2];
+#pragma unroll
+    for (int j = 0; j < L; j++) { xg[j][0] = pos_err[j]; xg[j][1] = vel[j]; swap32(xg[j][0], xg[j][1]); }
+    f32x16 acc[NI];
+    float h0[NI][4], h1[NI][4], part[NI];
+    auto ldq = [&](float (&d)[4], int slot) { float4 t = lds[slot][lane]; d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w; };
+    auto stq = [&](const float (&d)[4], int slot) { lds[slot][lane] = make_float4(d[0], d[1], d[2], d[3]); };
+    auto mf0 = [&](int i) {
+        const int j = i >> 1, g = i & 1;
+        ldq(h0[i], j * 8 + g);
+        f32x16 a = __builtin_amdgcn_mfma_f32_32x32x2f32(W.a[LW_B0], 1.0f, zero, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_32x32x2f32(W.a[LW_X], xg[j][g], a, 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < 4; s++) a = __builtin_amdgcn_mfma_f32_32x32x2f32(W.a[LW_H0 + s], h0[i][s], a, 0, 0, 0);
+        acc[i] = a;
+    };
+    auto cell0 = [&](int i) {
+        const int j = i >> 1, g = i & 1;
+        float c[4];
+        ldq(c, j * 8 + 2 + g);
+        lstm_cell(acc[i], h0[i], c);
+        stq(h0[i], j * 8 + g); stq(c, j * 8 + 2 + g);
+    };
+    auto mf1 = [&](int i) {
+        const int j = i >> 1, g = i & 1;
+        ldq(h1[i], j * 8 + 4 + g);
+        f32x16 a = __builtin_amdgcn_mfma_f32_32x32x2f32(W.a[LW_B1], 1.0f, zero, 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < 4; s++) a = __builtin_amdgcn_mfma_f32_32x32x2f32(W.a[LW_H1 + s], h1[i][s], a, 0, 0, 0);   // old h1 first: independent of cell0
+#pragma unroll
+        for (int s = 0; s < 4; s++) a = __builtin_amdgcn_mfma_f32_32x32x2f32(W.a[LW_I1 + s], h0[i][s], a, 0, 0, 0);
+        acc[i] = a;
+    };
+    auto cell1 = [&](int i) {
+        const int j = i >> 1, g = i & 1;
+        float c[4];
+        ldq(c, j * 8 + 6 + g);
+        lstm_cell(acc[i], h1[i], c);
+        stq(h1[i], j * 8 + 4 + g); stq(c, j * 8 + 6 + g);
+        float p = 0.0f;
+#pragma unroll
+        for (int u = 0; u < 4; u++) p += W.lw[u] * h1[i][u];
+        part[i] = p;
+    };
+#pragma unroll
+    for (int i = 0; i < NI; i++) { mf0(i); cell0(i); mf1(i); cell1(i); }
+#pragma unroll
+    for (int j = 0; j < L; j++) {
+        swap32(part[2 * j], part[2 * j + 1]);     // lanes < 32: (units 0-3, units 4-7) of group 0's row; lanes >= 32: group 1's
+        tau[j] = W.out_scale * ((part[2 * j] + part[2 * j + 1]) + W.lb);
+    }
 }
 
 }  // namespace lg

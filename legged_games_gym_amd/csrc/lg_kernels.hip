@@ -56,7 +56,38 @@ struct KArgs {                 // passed by value: lives in the kernarg segment 
     uint32_t   penalised_mask, termination_mask;
     unsigned int *done_counter;   // workgroup ticket of k_step (zeroed at create, self-resetting)
     int64_t    step;
+    unsigned long long *prof;     // LG_PROFILE builds only: [LG_NPROF] cycle accumulators (tools/profile_sections.py)
 };
+
+// ------------------------------------------------------------------ section profiler (debug builds: -DLG_PROFILE)
+#define LG_NPROF 16
+#ifdef LG_PROFILE
+// lane 0 of each workgroup accumulates s_memtime deltas per section in LDS and adds them to A.prof at the end.
+// idx < 0 starts the clock; slot 14 = whole kernel (s_memtime), slot 15 = whole kernel on the 100 MHz wall clock.
+__device__ __forceinline__ void lg_prof(int idx, unsigned long long *out) {
+    __shared__ unsigned long long acc[LG_NPROF], prev, t0, w0;
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned long long t = __builtin_readcyclecounter();
+    if (threadIdx.x == 0) {
+        if (idx < 0) { for (int i = 0; i < LG_NPROF; i++) acc[i] = 0; t0 = t; w0 = wall_clock64(); }
+        else acc[idx] += t - prev;
+        if (out) {
+            acc[14] = t - t0; acc[15] = wall_clock64() - w0;
+            for (int i = 0; i < LG_NPROF; i++) atomicAdd(out + i, acc[i]);
+        }
+        prev = __builtin_readcyclecounter();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+#define LG_PROF(i) lg_prof(i, nullptr)
+#define LG_PROF_BEGIN() lg_prof(-1, nullptr)
+#define LG_PROF_END(i, out) lg_prof(i, out)
+#else
+#define LG_PROF(i)
+#define LG_PROF_BEGIN()
+#define LG_PROF_END(i, out)
+#endif
+enum { PF_PROLOGUE = 0, PF_TORQUE, PF_KINEMATICS, PF_INWARD, PF_BASE, PF_OUTWARD, PF_INTEGRATE, PF_POST, PF_EXTRAS };
 
 // ------------------------------------------------------------------ terrain
 template <bool HF> LG_DEV void ground_query(const KArgs &A, float x, float y, float &h, V3 &n) {
@@ -242,6 +273,7 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, int lane_k, float 
         }
     }
 
+    LG_PROF(PF_KINEMATICS);
     // ---- articulated-body passes with the contact impedances folded in
     S6 U[L], acc0;
     float Dinv[L], uu[L], vl[L];      // vl: 0, or +-1 = joint speed limit active in that direction (set by the previous pass)
@@ -283,6 +315,7 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, int lane_k, float 
             pa = (pA + ai_mul(Ia, C[j])) + U[j] * (u * Dinv[j]);
             ai_shift(Ia, pa, db[j]);                 // to the parent's origin (the base origin for j == 0)
         }
+        LG_PROF(PF_INWARD);
         contact_assemble(cb, P, kn, Ia, pa);      // this lane's base point (about the base origin, like Ia after the shift)
         group_sum<K>(Ia, pa);                     // (limb0+limb1)+(limb2+limb3) on every lane of the env
         AI IAb = I0b; S6 pAb = p0b;
@@ -292,6 +325,7 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, int lane_k, float 
         if (!ok) { a0[0] = a0[1] = a0[2] = a0[3] = a0[4] = a0[5] = 0.0f; }
         acc0.w = v3(a0[0], a0[1], a0[2]); acc0.v = v3(a0[3], a0[4], a0[5]);
         contact_evaluate(cb, P, kn, mu, acc0);
+        LG_PROF(PF_BASE);
         S6 a = acc0;
 #pragma unroll
         for (int j = 0; j < L; j++) {
@@ -309,6 +343,7 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, int lane_k, float 
 #pragma unroll
             for (int i = 0; i < NPT; i++) if (T::pt_joint(i) == j) contact_evaluate(cl[i], P, kn, mu, a);
         }
+        LG_PROF(PF_OUTWARD);
     }
 
     // ---- semi-implicit Euler
@@ -340,6 +375,7 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, int lane_k, float 
         Frep[r][0] = f.x; Frep[r][1] = f.y; Frep[r][2] = f.z;
     }
     Fbase[0] = group_sum<K>(cb.f.x); Fbase[1] = group_sum<K>(cb.f.y); Fbase[2] = group_sum<K>(cb.f.z);
+    LG_PROF(PF_INTEGRATE);
 }
 
 // ------------------------------------------------------------------ torques (legged_robot.py:371-395)
@@ -384,6 +420,60 @@ LG_DEV float sample_height(const KArgs &A, const float *root, const float *qy, i
     int16_t h1 = H[ix * P.hf_cols + iy], h2 = H[(ix + 1) * P.hf_cols + iy], h3 = H[ix * P.hf_cols + iy + 1];
     int16_t h = h1 < h2 ? h1 : h2; h = h < h3 ? h : h3;
     return (float)h * P.hf_vertical_scale;
+}
+
+// Heights of this lane's chunks c = k, k+K, ... (4 points each), NB chunks per batch so 3*4*NB height-field gathers are in
+// flight before the first one is consumed (the samples are L2-resident but ~1 us away for a lone wave).  Results go to
+// measured_heights (the reference's buffer) and, as one float4 per chunk, to this lane's LDS column for the observation.
+#define LG_HSLOTS(K) (((LG_MAX_HEIGHT_POINTS + 3) / 4 + (K) - 1) / (K))
+template <class T, bool HF>
+LG_DEV float sample_heights(const KArgs &A, int e, int k, bool live, const float *root, float4 (*lds_h)[LG_BLOCK]) {
+    constexpr int K = T::K, NB = 4;
+    const lg_params &P = A.P;
+    float qy[4] = {0, 0, root[5], root[6]};
+    float nrm = fmaxf(sqrtf(qy[2] * qy[2] + qy[3] * qy[3]), 1e-9f);
+    qy[2] /= nrm; qy[3] /= nrm;
+    float *mh = A.B.measured_heights + (size_t)e * P.num_height_points;
+    const int np = P.num_height_points, nchunk = (np + 3) >> 2;
+    const int16_t *H = A.B.height_samples;
+    float hsum = 0.0f;
+    int slot = 0;
+    for (int c0 = k; c0 < nchunk; c0 += K * NB, slot += NB) {
+        int16_t s0[NB][4], s1[NB][4], s2[NB][4];
+        if (HF) {
+#pragma unroll
+            for (int b = 0; b < NB; b++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    int i = min(4 * (c0 + b * K) + t, np - 1);                     // clamped: the tail re-reads a valid point
+                    V3 p = quat_apply(qy, v3(P.height_points[i][0], P.height_points[i][1], 0.0f));
+                    float px = p.x + root[0] + P.hf_border, py = p.y + root[1] + P.hf_border;
+                    int ix = (int)(px / P.hf_horizontal_scale), iy = (int)(py / P.hf_horizontal_scale);   // .long(): truncation; int32 saturates, then clamps
+                    ix = min(max(ix, 0), P.hf_rows - 2); iy = min(max(iy, 0), P.hf_cols - 2);
+                    const int16_t *hp = H + ix * P.hf_cols + iy;                 // rows x cols < 2^31 (checked at bind)
+                    s0[b][t] = hp[0]; s1[b][t] = hp[P.hf_cols]; s2[b][t] = hp[1];
+                }
+        }
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            const int c = c0 + b * K;
+            float hh[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                float h = 0.0f;
+                if (HF) {
+                    int16_t m = s0[b][t] < s1[b][t] ? s0[b][t] : s1[b][t];
+                    m = m < s2[b][t] ? m : s2[b][t];
+                    h = (float)m * P.hf_vertical_scale;
+                }
+                hh[t] = h;
+                const int i = 4 * c + t;
+                if (i < np) { if (live) mh[i] = h; hsum += root[2] - h; }
+            }
+            if (c < nchunk) lds_h[slot + b][threadIdx.x] = make_float4(hh[0], hh[1], hh[2], hh[3]);
+        }
+    }
+    return hsum;
 }
 
 // New state of a reset environment (reset_idx :147-191).  Every lane of the env computes the shared part
@@ -433,7 +523,7 @@ LG_DEV void reset_values(const KArgs &A, const float *tab, int e, int k, int64_t
 template <class T>
 LG_DEV void write_observations(const KArgs &A, int e, int k, bool live, int64_t step, const float *root, const float (&q)[T::L],
                                const float (&qd)[T::L], const float (&act)[T::L], const float *tab, V3 blv, V3 bav, V3 pg,
-                               const float (&cmd)[4]) {
+                               const float (&cmd)[4], const float4 (*lds_h)[LG_BLOCK] /* this step's heights, or null: read the buffer */) {
     constexpr int K = T::K, L = T::L;
     const lg_params &P = A.P;
     float head[12] = {blv.x * P.obs_scale_lin_vel, blv.y * P.obs_scale_lin_vel, blv.z * P.obs_scale_lin_vel,
@@ -475,14 +565,20 @@ LG_DEV void write_observations(const KArgs &A, int e, int k, bool live, int64_t 
     if (P.measure_heights) {
         const float *mh = A.B.measured_heights + (size_t)e * P.num_height_points;
         const int nchunk = (P.num_height_points + 3) >> 2;
-        for (int c = k; c < nchunk; c += K) {          // chunk c = points 4c..4c+3, one Philox block each
-            float u[4] = {0, 0, 0, 0};
+        int slot = 0;
+        for (int c = k; c < nchunk; c += K, slot++) {  // chunk c = points 4c..4c+3, one Philox block each
+            float u[4] = {0, 0, 0, 0}, hv[4];
+            if (lds_h) { float4 t4 = lds_h[slot][threadIdx.x]; hv[0] = t4.x; hv[1] = t4.y; hv[2] = t4.z; hv[3] = t4.w; }
+            else {
+#pragma unroll
+                for (int t = 0; t < 4; t++) hv[t] = mh[min(4 * c + t, P.num_height_points - 1)];
+            }
             if (P.add_noise) rand4(P.seed, e, step, RNG_NOISE_H, c, u);
 #pragma unroll
             for (int t = 0; t < 4; t++) {
                 int i = 4 * c + t;
                 if (i < P.num_height_points) {
-                    float h = root[2] - 0.5f - mh[i];
+                    float h = root[2] - 0.5f - hv[t];
                     float o = fminf(fmaxf(h, -1.0f), 1.0f) * P.obs_scale_height;
                     if (P.add_noise) o += (2.0f * u[t] - 1.0f) * P.noise_height;
                     o = fminf(fmaxf(o, -P.clip_observations), P.clip_observations);
@@ -530,6 +626,8 @@ __global__ void __launch_bounds__(LG_BLOCK) k_step(const KArgs A) {
     const lg_buffers &B = A.B;
     __shared__ float lds_tab[T::K * Tab<T>::STRIDE];
     __shared__ float4 lds_lstm[NET ? L * 8 : 1][LG_BLOCK];      // [joint*8 + quarter(h0 lo,h0 hi,c0..,h1..,c1..)][lane]
+    __shared__ float4 lds_h[LG_HSLOTS(K)][LG_BLOCK];            // this step's measured heights, [chunk slot of the lane][lane]
+    LG_PROF_BEGIN();
     stage_limb_table<T>(A, lds_tab);
 
     const int N = P.num_envs;
@@ -592,29 +690,18 @@ __global__ void __launch_bounds__(LG_BLOCK) k_step(const KArgs A) {
 #pragma unroll
         for (int j = 0; j < L; j++) tau[j] = B.torques[d0 + j];
     }
+    LG_PROF(PF_PROLOGUE);
 #pragma unroll 1
     for (int it = 0; it < P.decimation; it++) {
         if (NET) {
-#pragma unroll 1
-            for (int j = 0; j < L; j++) {
-                LstmSplit st;
-                float4 t;
-#define LD(dst, slot) t = lds_lstm[j * 8 + slot][threadIdx.x]; dst[0] = t.x; dst[1] = t.y; dst[2] = t.z; dst[3] = t.w;
-                LD(st.h0[0], 0) LD(st.h0[1], 1) LD(st.c0[0], 2) LD(st.c0[1], 3) LD(st.h1[0], 4) LD(st.h1[1], 5) LD(st.c1[0], 6) LD(st.c1[1], 7)
-#undef LD
-                float qj = 0, qdj = 0, aj = 0, q0j = tab[j * LG_JS + J_Q0];
+            float perr[L];
 #pragma unroll
-                for (int jj = 0; jj < L; jj++) if (jj == j) { qj = q[jj]; qdj = qd[jj]; aj = act[jj]; }
-                float t_out = actuator_step_mfma(LW, aj * P.action_scale + q0j - qj, qdj, st);
-#pragma unroll
-                for (int jj = 0; jj < L; jj++) if (jj == j) tau[jj] = t_out;
-#define ST(src, slot) lds_lstm[j * 8 + slot][threadIdx.x] = make_float4(src[0], src[1], src[2], src[3]);
-                ST(st.h0[0], 0) ST(st.h0[1], 1) ST(st.c0[0], 2) ST(st.c0[1], 3) ST(st.h1[0], 4) ST(st.h1[1], 5) ST(st.c1[0], 6) ST(st.c1[1], 7)
-#undef ST
-            }
+            for (int j = 0; j < L; j++) perr[j] = act[j] * P.action_scale + tab[j * LG_JS + J_Q0] - q[j];
+            actuator_substep_mfma<L, LG_BLOCK>(LW, lds_lstm, perr, qd, tau);
         } else {
             pd_torques<L>(P, tab, act, q, qd, last_qd, tau);
         }
+        LG_PROF(PF_TORQUE);
         physics_substep<T, HF>(A, tab, k, root, q, qd, tau, base_mass, mu, Frep, Fbase);
     }
 
@@ -637,21 +724,7 @@ __global__ void __launch_bounds__(LG_BLOCK) k_step(const KArgs A) {
     if (P.measure_heights) {
         // lane k samples (and later consumes, in the observation) the points of chunks c = k, k+K, ...:
         // no other lane ever reads what this lane writes, so no barrier is needed.
-        float qy[4] = {0, 0, root[5], root[6]};
-        float nrm = fmaxf(sqrtf(qy[2] * qy[2] + qy[3] * qy[3]), 1e-9f);
-        qy[2] /= nrm; qy[3] /= nrm;
-        float *mh = B.measured_heights + (size_t)e * P.num_height_points;
-        const int nchunk = (P.num_height_points + 3) >> 2;
-        for (int c = k; c < nchunk; c += K)
-#pragma unroll
-            for (int t = 0; t < 4; t++) {
-                int i = 4 * c + t;
-                if (i < P.num_height_points) {
-                    float h = HF ? sample_height(A, root, qy, i) : 0.0f;
-                    if (live) mh[i] = h;
-                    hsum += root[2] - h;
-                }
-            }
+        hsum = sample_heights<T, HF>(A, e, k, live, root, lds_h);
     }
     if (P.push_interval > 0 && step % P.push_interval == 0) {                     // _push_robots :438-444
         float u[4];
@@ -796,7 +869,7 @@ __global__ void __launch_bounds__(LG_BLOCK) k_step(const KArgs A) {
     }
 
     // compute_observations :130 (stale base-frame quantities for reset envs, as in the reference)
-    write_observations<T>(A, e, k, live, step, root, q, qd, act, tab, blv, bav, pg, cmd);
+    write_observations<T>(A, e, k, live, step, root, q, qd, act, tab, blv, bav, pg, cmd, lds_h);
 
     // ---- write persistent state back (written once per env-step)
     if (NET) {      // unit-split -> per-row 8-vectors (needs every lane of the wave), zeroed for reset envs
@@ -853,6 +926,7 @@ __global__ void __launch_bounds__(LG_BLOCK) k_step(const KArgs A) {
     // have drained (s_waitcnt vmcnt(0)), and the finisher reads with device-scope (L1-bypassing) loads.
     __shared__ int s_last;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    LG_PROF(PF_POST);
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned int ticket = atomicAdd(A.done_counter, 1u);
@@ -861,6 +935,7 @@ __global__ void __launch_bounds__(LG_BLOCK) k_step(const KArgs A) {
     }
     __syncthreads();
     if (s_last) finish_extras(A, threadIdx.x, step, true);
+    LG_PROF_END(PF_EXTRAS, A.prof);
 }
 
 // ------------------------------------------------------------------ reset_idx on an id list (base_task.py:114-118)
@@ -1032,7 +1107,7 @@ __global__ void __launch_bounds__(LG_BLOCK) k_obs(const KArgs A) {
     V3 blv = v3(B.base_lin_vel[(size_t)e * 3], B.base_lin_vel[(size_t)e * 3 + 1], B.base_lin_vel[(size_t)e * 3 + 2]);
     V3 bav = v3(B.base_ang_vel[(size_t)e * 3], B.base_ang_vel[(size_t)e * 3 + 1], B.base_ang_vel[(size_t)e * 3 + 2]);
     V3 pg = v3(B.projected_gravity[(size_t)e * 3], B.projected_gravity[(size_t)e * 3 + 1], B.projected_gravity[(size_t)e * 3 + 2]);
-    write_observations<T>(A, e, k, live, A.step, root, q, qd, act, tab, blv, bav, pg, cmd);
+    write_observations<T>(A, e, k, live, A.step, root, q, qd, act, tab, blv, bav, pg, cmd, nullptr);
 }
 
 // ====================================================================  host side: C-ABI  ====================================================================
@@ -1053,6 +1128,7 @@ struct lg_sim {
     float         *d_limb_table;
     float         *d_weights;
     unsigned int  *d_done;
+    unsigned long long *d_prof;
 };
 
 template <class T> static int check_topology(const lg_robot_model *m) {
@@ -1098,13 +1174,16 @@ static void build_lstm_table(const float *w, float *t /* [LW_ROWS][64] */) {
     const float *Wih1 = bhh0 + 32, *Whh1 = Wih1 + 256, *bih1 = Whh1 + 256, *bhh1 = bih1 + 32, *lw = bhh1 + 32, *lb = lw + 8;
     for (int l = 0; l < 64; l++) {
         const int g = l & 31, hb = l >> 5;
-        t[LW_B0 * 64 + l] = hb ? 0.0f : bih0[g] + bhh0[g];
-        t[LW_X * 64 + l] = Wih0[2 * g + hb] * in_scale[hb];
-        t[LW_B1 * 64 + l] = hb ? 0.0f : bih1[g] + bhh1[g];
+        // gate rows are pre-scaled so lstm_cell can feed v_exp_f32 (= 2^x) directly: i, f, o by -log2(e); g (rows 16-23) by -2 log2(e)
+        const double sc = (g >= 16 && g < 24) ? -2.0 * 1.4426950408889634 : -1.4426950408889634;
+        auto S = [&](double v) { return (float)(sc * v); };
+        t[LW_B0 * 64 + l] = hb ? 0.0f : S((double)bih0[g] + (double)bhh0[g]);
+        t[LW_X * 64 + l] = S((double)Wih0[2 * g + hb] * in_scale[hb]);
+        t[LW_B1 * 64 + l] = hb ? 0.0f : S((double)bih1[g] + (double)bhh1[g]);
         for (int s = 0; s < 4; s++) {
-            t[(LW_H0 + s) * 64 + l] = Whh0[8 * g + s + 4 * hb];
-            t[(LW_I1 + s) * 64 + l] = Wih1[8 * g + s + 4 * hb];
-            t[(LW_H1 + s) * 64 + l] = Whh1[8 * g + s + 4 * hb];
+            t[(LW_H0 + s) * 64 + l] = S(Whh0[8 * g + s + 4 * hb]);
+            t[(LW_I1 + s) * 64 + l] = S(Wih1[8 * g + s + 4 * hb]);
+            t[(LW_H1 + s) * 64 + l] = S(Whh1[8 * g + s + 4 * hb]);
             t[(LW_LIN + s) * 64 + l] = lw[s + 4 * hb];
         }
         t[LW_LB * 64 + l] = lb[0];
@@ -1129,7 +1208,7 @@ static int upload_tables(lg_sim *s) {
 static void fill_args(const lg_sim *s, KArgs &a, int64_t step) {
     a.P = s->P; a.B = s->B; a.base = s->base; a.limb_table = s->d_limb_table; a.weights = s->d_weights;
     a.actions_in = nullptr; a.env_ids = nullptr; a.count = 0; a.step = step;
-    a.penalised_mask = s->M.penalised_mask; a.termination_mask = s->M.termination_mask; a.done_counter = s->d_done;
+    a.penalised_mask = s->M.penalised_mask; a.termination_mask = s->M.termination_mask; a.done_counter = s->d_done; a.prof = s->d_prof;
 }
 template <class T> static int grid_for(int n_env_like) { return (n_env_like * T::K + LG_BLOCK - 1) / LG_BLOCK; }
 
@@ -1215,6 +1294,16 @@ int lg_policy_act(lg_policy *p, const float *obs, float *actions, float *mean, i
 
 const char *lg_last_error(void) { return g_err; }
 int lg_abi_version(void) { return LG_ABI_VERSION; }
+#ifdef LG_PROFILE
+// debug builds only (not part of legged_hip.h): copy out and optionally clear the k_step section accumulators
+int lg_debug_profile(lg_sim *s, unsigned long long *out16, int reset) {
+    if (!s || !s->d_prof) return -1;
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    if (hipMemcpy(out16, s->d_prof, sizeof(unsigned long long) * LG_NPROF, hipMemcpyDeviceToHost) != hipSuccess) return -2;
+    if (reset && hipMemset(s->d_prof, 0, sizeof(unsigned long long) * LG_NPROF) != hipSuccess) return -2;
+    return 0;
+}
+#endif
 int lg_sizeof(int which) {
     switch (which) { case 0: return (int)sizeof(lg_params); case 1: return (int)sizeof(lg_robot_model);
                      case 2: return (int)sizeof(lg_buffers); case 3: return (int)sizeof(lg_point); default: return -1; }
@@ -1235,9 +1324,12 @@ int lg_create(const lg_params *params, const lg_robot_model *model, const float 
     lg_sim *s = new (std::nothrow) lg_sim();
     if (!s) return fail(-5, "out of host memory");
     s->P = *params; s->M = *model; s->kind = kind; s->device = device_id; s->bound = false;
-    s->has_net = actuator_weights != nullptr; s->d_weights = nullptr; s->d_limb_table = nullptr; s->d_done = nullptr;
+    s->has_net = actuator_weights != nullptr; s->d_weights = nullptr; s->d_limb_table = nullptr; s->d_done = nullptr; s->d_prof = nullptr;
     if (hipMalloc(&s->d_done, sizeof(unsigned int)) != hipSuccess || hipMemset(s->d_done, 0, sizeof(unsigned int)) != hipSuccess) { delete s; return fail(-10, "hipMalloc failed"); }
     memset(&s->B, 0, sizeof s->B);
+#ifdef LG_PROFILE
+    if (hipMalloc(&s->d_prof, sizeof(unsigned long long) * LG_NPROF) != hipSuccess || hipMemset(s->d_prof, 0, sizeof(unsigned long long) * LG_NPROF) != hipSuccess) { delete s; return fail(-10, "hipMalloc failed"); }
+#endif
     if (hipMalloc(&s->d_limb_table, sizeof(float) * LG_MAX_LIMBS * (LG_MAX_CHAIN * LG_JS + 4 * LG_MAX_LIMB_POINTS + 1)) != hipSuccess) { delete s; return fail(-10, "hipMalloc failed"); }
     if (s->has_net) {
         float table[LW_ROWS * 64];
@@ -1256,6 +1348,7 @@ void lg_destroy(lg_sim *s) {
     if (s->d_limb_table) (void)hipFree(s->d_limb_table);
     if (s->d_weights) (void)hipFree(s->d_weights);
     if (s->d_done) (void)hipFree(s->d_done);
+    if (s->d_prof) (void)hipFree(s->d_prof);
     delete s;
 }
 
@@ -1269,6 +1362,8 @@ int lg_bind(lg_sim *s, const lg_buffers *b) {
     if (s->P.control_type == LG_CTRL_ACTUATOR_NET && (!b->sea_hidden_state || !b->sea_cell_state)) return fail(-6, "actuator state buffers missing");
     if (s->P.measure_heights && !b->measured_heights) return fail(-6, "measured_heights buffer missing");
     if (s->P.terrain_type == LG_TERRAIN_HEIGHTFIELD && !b->height_samples) return fail(-6, "height_samples missing");
+    if (s->P.terrain_type == LG_TERRAIN_HEIGHTFIELD && (s->P.hf_rows < 2 || s->P.hf_cols < 2 || (int64_t)s->P.hf_rows * s->P.hf_cols > 0x7fffffff))
+        return fail(-6, "height field must have 2 <= rows, cols and rows*cols < 2^31");
     if (s->P.terrain_curriculum && (!b->terrain_levels || !b->terrain_types || !b->terrain_origins)) return fail(-6, "terrain curriculum buffers missing");
     s->B = *b; s->bound = true;
     return 0;

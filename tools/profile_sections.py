@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Where does k_step spend its time?  Builds the HIP sources with -DLG_PROFILE (s_memtime section counters, lane 0 of
+every workgroup), runs the bench workload for a few hundred steps and prints the per-section share.
+
+  python tools/profile_sections.py build            # here (hipcc cross-compiles) -> csrc/liblegged_hip_prof.so
+  python tools/profile_sections.py run [task] [N]   # on the GPU box
+"""
+import ctypes, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.realpath(__file__)))
+sys.path.insert(0, ROOT)
+CSRC = os.path.join(ROOT, "legged_games_gym_amd", "csrc")
+LIB = os.path.join(CSRC, "liblegged_hip_prof.so")
+NAMES = ["prologue (tables, state loads)", "torques (actuator LSTM / PD)", "kinematics + body terms + contact setup", "inward ABA recursion (per pass)",
+         "base: butterfly + 6x6 solve", "outward accelerations + contact evaluate", "integrate + force sums", "post-physics (rewards, reset, obs)", "extras finisher"]
+
+if sys.argv[1:2] == ["build"]:
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-fno-slp-vectorize",
+           "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-mllvm", "-amdgpu-mfma-vgpr-form", "-DLG_PROFILE", "-o", LIB, os.path.join(CSRC, "lg_kernels.hip")]
+    print(" ".join(cmd)); subprocess.run(cmd, check=True); sys.exit(0)
+
+os.environ["LG_HIP_LIB"] = LIB
+import torch
+from legged_games_gym_amd import capi
+from legged_games_gym_amd.envs import task_registry
+from legged_games_gym_amd.utils import get_args
+task = sys.argv[2] if len(sys.argv) > 2 else "anymal_c_flat"
+n = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
+args = get_args(["--task", task, "--num_envs", str(n), "--headless", "--sim_device", "cuda:0", "--rl_device", "cuda:0"])
+env, cfg = task_registry.make_env(task, args)
+lib = capi.load_library()
+lib.lg_debug_profile.argtypes, lib.lg_debug_profile.restype = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int], ctypes.c_int
+out = (ctypes.c_uint64 * 16)()
+g = torch.Generator(device="cuda").manual_seed(0)
+for _ in range(50):
+    env.step(torch.randn(env.num_envs, env.num_actions, device="cuda", generator=g))
+handle = env._sim.sim.handle
+assert lib.lg_debug_profile(handle, out, 1) == 0
+steps = 300
+t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+acts = [torch.randn(env.num_envs, env.num_actions, device="cuda", generator=g) for _ in range(8)]
+t0.record()
+for i in range(steps):
+    env.step(acts[i % 8])
+t1.record(); torch.cuda.synchronize()
+assert lib.lg_debug_profile(handle, out, 0) == 0
+v = [int(x) for x in out]
+wgs = steps * ((env.num_envs * (2 if task == "cassie" else 4) + 63) // 64)
+tot, wall = v[14] / wgs, v[15] / wgs * 10.0          # cycles per workgroup-step; ns (100 MHz wall clock)
+print(f"{task} N={env.num_envs}: {t0.elapsed_time(t1) / steps * 1e3:.1f} us per env.step (instrumented build); per workgroup {tot:.0f} cycles = {wall / 1e3:.1f} us -> {tot / wall:.2f} GHz counter")
+for i, name in enumerate(NAMES):
+    c = v[i] / wgs
+    print(f"  {name:45s} {c:9.0f} cyc  {c / tot * 100:5.1f} %  {c / tot * wall / 1e3:6.2f} us")
+print(f"  {'(unattributed)':45s} {tot - sum(v[:9]) / wgs:9.0f} cyc")

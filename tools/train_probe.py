@@ -11,6 +11,8 @@ args = get_args(["--task", task, "--headless", "--sim_device", "cuda:0", "--rl_d
 env_cfg, train_cfg0 = task_registry.get_cfgs(task)
 if os.environ.get("LG_SEED"):            # the env seeds from the registered train cfg (reference quirk), not from --seed
     train_cfg0.seed = int(os.environ["LG_SEED"])
+if os.environ.get("LG_ENTROPY"):
+    train_cfg0.algorithm.entropy_coef = float(os.environ["LG_ENTROPY"])
 if os.environ.get("LG_UNCLIPPED"):
     env_cfg.rewards.only_positive_rewards = False
 if os.environ.get("LG_INIT_STD"):
