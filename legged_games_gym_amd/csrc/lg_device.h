@@ -330,68 +330,4 @@ LG_DEV float actuator_step_mfma(const LstmLane &W, float pos_err, float vel, Lst
 }
 
 
-// All L joints of this lane for one sub-step: 2 L independent (joint, group) instances, fully unrolled so the bias
-// MFMAs (identical for every instance) are computed once and reused as the C operand.  `lds` is the parked unit-split
-// state: [joint * 8 + {h0,c0,h1,c1} * 2 + group][lane].  Measured on MI355X (tools/ubench/mfma_overlap.hip): a lone wave
-// does NOT overlap its own MFMA and VALU instructions (1 MFMA + 8 FMA = 49 ns vs 27 + 24 ns), so instance order is
-// irrelevant and the cost is simply 80 x 27 ns of matrix pipe + ~1200 vector instructions per sub-step.
-// Must be executed with all 64 lanes active.
-template <int L, int BLOCK>
-LG_DEV void actuator_substep_mfma(const LstmLane &W, float4 (*lds)[BLOCK], const float (&pos_err)[L], const float (&vel)[L], float (&tau)[L]) {
-    constexpr int NI = 2 * L;
-    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const int lane = threadIdx.x;
-    float xg[L][2];
-#pragma unroll
-    for (int j = 0; j < L; j++) { xg[j][0] = pos_err[j]; xg[j][1] = vel[j]; swap32(xg[j][0], xg[j][1]); }
-    f32x16 acc[NI];
-    float h0[NI][4], h1[NI][4], part[NI];
-    auto ldq = [&](float (&d)[4], int slot) { float4 t = lds[slot][lane]; d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w; };
-    auto stq = [&](const float (&d)[4], int slot) { lds[slot][lane] = make_float4(d[0], d[1], d[2], d[3]); };
-    auto mf0 = [&](int i) {
-        const int j = i >> 1, g = i & 1;
-        ldq(h0[i], j * 8 + g);
-        f32x16 a = __builtin_amdgcn_mfma_f32_32x32x2f32(W.a[LW_B0], 1.0f, zero, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_32x32x2f32(W.a[LW_X], xg[j][g], a, 0, 0, 0);
-#pragma unroll
-        for (int s = 0; s < 4; s++) a = __builtin_amdgcn_mfma_f32_32x32x2f32(W.a[LW_H0 + s], h0[i][s], a, 0, 0, 0);
-        acc[i] = a;
-    };
-    auto cell0 = [&](int i) {
-        const int j = i >> 1, g = i & 1;
-        float c[4];
-        ldq(c, j * 8 + 2 + g);
-        lstm_cell(acc[i], h0[i], c);
-        stq(h0[i], j * 8 + g); stq(c, j * 8 + 2 + g);
-    };
-    auto mf1 = [&](int i) {
-        const int j = i >> 1, g = i & 1;
-        ldq(h1[i], j * 8 + 4 + g);
-        f32x16 a = __builtin_amdgcn_mfma_f32_32x32x2f32(W.a[LW_B1], 1.0f, zero, 0, 0, 0);
-#pragma unroll
-        for (int s = 0; s < 4; s++) a = __builtin_amdgcn_mfma_f32_32x32x2f32(W.a[LW_H1 + s], h1[i][s], a, 0, 0, 0);   // old h1 first: independent of cell0
-#pragma unroll
-        for (int s = 0; s < 4; s++) a = __builtin_amdgcn_mfma_f32_32x32x2f32(W.a[LW_I1 + s], h0[i][s], a, 0, 0, 0);
-        acc[i] = a;
-    };
-    auto cell1 = [&](int i) {
-        const int j = i >> 1, g = i & 1;
-        float c[4];
-        ldq(c, j * 8 + 6 + g);
-        lstm_cell(acc[i], h1[i], c);
-        stq(h1[i], j * 8 + 4 + g); stq(c, j * 8 + 6 + g);
-        float p = 0.0f;
-#pragma unroll
-        for (int u = 0; u < 4; u++) p += W.lw[u] * h1[i][u];
-        part[i] = p;
-    };
-#pragma unroll
-    for (int i = 0; i < NI; i++) { mf0(i); cell0(i); mf1(i); cell1(i); }
-#pragma unroll
-    for (int j = 0; j < L; j++) {
-        swap32(part[2 * j], part[2 * j + 1]);     // lanes < 32: (units 0-3, units 4-7) of group 0's row; lanes >= 32: group 1's
-        tau[j] = W.out_scale * ((part[2 * j] + part[2 * j + 1]) + W.lb);
-    }
-}
-
 }  // namespace lg

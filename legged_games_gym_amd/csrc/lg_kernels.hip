@@ -166,10 +166,13 @@ LG_DEV V3 clamp_norm(V3 a, float lim) {           // asset.max_linear/angular_ve
     return a;
 }
 
-template <class T, bool HF>
+// `torques_ready` runs between the kinematics half (needs no torques) and the articulated-body passes: the fused step
+// uses it to join the actuator waves, which compute this sub-step's torques meanwhile (k_step).
+struct NoWait { LG_DEV void operator()() const {} };
+template <class T, bool HF, class Ready = NoWait>
 LG_DEV void physics_substep(const KArgs &A, const float *tab, int lane_k, float (&root)[13], float (&q)[T::L], float (&qd)[T::L],
                             const float (&tau)[T::L], float base_mass, float mu,
-                            float (&Frep)[T::NREP][3], float (&Fbase)[3]) {
+                            float (&Frep)[T::NREP][3], float (&Fbase)[3], Ready torques_ready = Ready()) {
     constexpr int K = T::K, L = T::L, NPT = T::NPT;
     const lg_params &P = A.P;
     const float dt = P.sim_dt;
@@ -274,6 +277,8 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, int lane_k, float 
     }
 
     LG_PROF(PF_KINEMATICS);
+    torques_ready();
+    LG_PROF(PF_TORQUE);
     // ---- articulated-body passes with the contact impedances folded in
     S6 U[L], acc0;
     float Dinv[L], uu[L], vl[L];      // vl: 0, or +-1 = joint speed limit active in that direction (set by the previous pass)
@@ -604,6 +609,7 @@ LG_DEV void finish_extras(const KArgs &A, int t, int64_t step_used, bool publish
     float cnt = __hip_atomic_load(A.B.extras_accum + R, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     float v = (t < R) ? __hip_atomic_load(A.B.extras_accum + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
     __syncthreads();
+    if (t >= 64) return;                            // blocks wider than one wave (k_step with actuator waves): wave 0 finishes
     if (t < R) {
         if (cnt > 0.0f) A.B.episode_means[t] = v / cnt / P.max_episode_length_s;
         __hip_atomic_store(A.B.extras_accum + t, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -619,19 +625,68 @@ LG_DEV void finish_extras(const KArgs &A, int t, int64_t step_used, bool publish
     }
 }
 // ------------------------------------------------------------------ THE fused policy-step kernel
+// One workgroup = 64 (env, limb) lanes.  A lone wave issues one instruction every ~6.5 cycles and cannot overlap its own
+// MFMA and VALU work (tools/ubench), and at 4096 envs only one wave per CU exists -- so with the actuator net the workgroup
+// is WAVE-SPECIALISED across the CU's four SIMDs: wave 0 runs the rigid-body step, waves 1..L own the LSTM of joint 0..L-1
+// of every lane (state resident in their registers for the whole step) and compute each sub-step's torques while wave 0
+// does the torque-independent kinematics half.  Hand-over through LDS (lds_x -> lds_tau), two barriers per sub-step.
+template <class T> struct ActuatorWave {
+    // joint j of (env, limb) lane `lane`; must be executed by all 64 lanes of the wave
+    static LG_DEV void run(const KArgs &A, int j, int lane, int d0, bool live, float2 (*lds_x)[LG_BLOCK], float (*lds_tau)[LG_BLOCK], const int *lds_rst) {
+        const lg_buffers &B = A.B;
+        const size_t plane = (size_t)A.P.num_envs * (T::K * T::L);
+        const LstmLane LW = lstm_load(A.weights, lane);
+        float *row[4] = {B.sea_hidden_state + (size_t)(d0 + j) * 8, B.sea_cell_state + (size_t)(d0 + j) * 8,
+                         B.sea_hidden_state + (plane + d0 + j) * 8, B.sea_cell_state + (plane + d0 + j) * 8};   // h0, c0, h1, c1 (anymal.py:65-69)
+        LstmSplit st;
+        float (*part[4])[4] = {st.h0, st.c0, st.h1, st.c1};
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+            float4 lo = reinterpret_cast<const float4 *>(row[a])[0], hi = reinterpret_cast<const float4 *>(row[a])[1];
+            float u[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            lstm_split(u, part[a][0], part[a][1]);
+        }
+        for (int it = 0; it < A.P.decimation; it++) {
+            __syncthreads();                                   // this sub-step's (pos_err, vel) are in lds_x
+            const float2 x = lds_x[j][lane];
+            lds_tau[j][lane] = actuator_step_mfma(LW, x.x, x.y, st);
+            __syncthreads();                                   // torques published
+        }
+        __syncthreads();                                       // reset flags published
+        const bool reset = lds_rst[lane] != 0;
+#pragma unroll
+        for (int a = 0; a < 4; a++) {                          // unit-split -> per-row 8-vectors, zeroed for reset envs (anymal.py:59-60)
+            float u[8];
+            lstm_unsplit(part[a][0], part[a][1], u);
+            if (reset) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) u[i] = 0.0f;
+            }
+            if (live) {
+                reinterpret_cast<float4 *>(row[a])[0] = make_float4(u[0], u[1], u[2], u[3]);
+                reinterpret_cast<float4 *>(row[a])[1] = make_float4(u[4], u[5], u[6], u[7]);
+            }
+        }
+    }
+};
+
 template <class T, bool NET, bool HF>
-__global__ void __launch_bounds__(LG_BLOCK) k_step(const KArgs A) {
+__global__ void __launch_bounds__(NET ? (1 + T::L) * LG_BLOCK : LG_BLOCK) k_step(const KArgs A) {
     constexpr int K = T::K, L = T::L, ND = K * L, NREP = T::NREP;
     const lg_params &P = A.P;
     const lg_buffers &B = A.B;
     __shared__ float lds_tab[T::K * Tab<T>::STRIDE];
-    __shared__ float4 lds_lstm[NET ? L * 8 : 1][LG_BLOCK];      // [joint*8 + quarter(h0 lo,h0 hi,c0..,h1..,c1..)][lane]
     __shared__ float4 lds_h[LG_HSLOTS(K)][LG_BLOCK];            // this step's measured heights, [chunk slot of the lane][lane]
+    __shared__ float2 lds_x[NET ? L : 1][LG_BLOCK];             // actuator inputs (pos_err, vel) of the sub-step, [joint][lane]
+    __shared__ float lds_tau[NET ? L : 1][LG_BLOCK];            // actuator torques of the sub-step
+    __shared__ int lds_rst[LG_BLOCK];                           // reset flag of the lane's env, for the actuator waves' write-back
+    __shared__ int s_last;
     LG_PROF_BEGIN();
     stage_limb_table<T>(A, lds_tab);
 
     const int N = P.num_envs;
-    const int tid = blockIdx.x * LG_BLOCK + threadIdx.x;
+    const int wave = NET ? (int)(threadIdx.x / LG_BLOCK) : 0, lane = threadIdx.x % LG_BLOCK;
+    const int tid = blockIdx.x * LG_BLOCK + lane;
     int e = tid / K;
     const int k = tid % K;
     const bool live = e < N;
@@ -640,6 +695,9 @@ __global__ void __launch_bounds__(LG_BLOCK) k_step(const KArgs A) {
     const int d0 = e * ND + k * L;                                // first dof of this lane
     const int64_t step = A.step >= 0 ? A.step : B.step_counter[0] + 1;   // -1: self-advancing (HIP-graph replay)
 
+    if (NET && wave > 0) {
+        ActuatorWave<T>::run(A, wave - 1, lane, d0, live, lds_x, lds_tau, lds_rst);
+    } else {
     // ---- load persistent state (read once per env-step)
     float root[13], q[L], qd[L], act[L], tau[L];
 #pragma unroll
@@ -651,25 +709,6 @@ __global__ void __launch_bounds__(LG_BLOCK) k_step(const KArgs A) {
         float a = A.actions_in[d0 + j];
         act[j] = fminf(fmaxf(a, -P.clip_actions), P.clip_actions);       // :86-87
         tau[j] = 0.0f;
-    }
-    const size_t plane = (size_t)N * ND;
-    LstmLane LW;
-    if (NET) {
-        LW = lstm_load(A.weights, threadIdx.x & 63);
-        // actuator state: global (per-row 8-vectors) -> unit-split MFMA layout, parked in LDS between uses
-#pragma unroll
-        for (int j = 0; j < L; j++) {
-            const float *src[4] = {B.sea_hidden_state + (size_t)(d0 + j) * 8, B.sea_cell_state + (size_t)(d0 + j) * 8,
-                                   B.sea_hidden_state + (plane + d0 + j) * 8, B.sea_cell_state + (plane + d0 + j) * 8};
-#pragma unroll
-            for (int a = 0; a < 4; a++) {
-                float4 lo = reinterpret_cast<const float4 *>(src[a])[0], hi = reinterpret_cast<const float4 *>(src[a])[1];
-                float u[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}, g0[4], g1[4];
-                lstm_split(u, g0, g1);
-                lds_lstm[j * 8 + 2 * a][threadIdx.x] = make_float4(g0[0], g0[1], g0[2], g0[3]);
-                lds_lstm[j * 8 + 2 * a + 1][threadIdx.x] = make_float4(g1[0], g1[1], g1[2], g1[3]);
-            }
-        }
     }
     const float mu = 0.5f * ((B.friction_coeffs ? B.friction_coeffs[e] : 1.0f) + P.ground_friction);
     const float base_mass = A.base.mass + (B.base_mass_delta ? B.base_mass_delta[e] : 0.0f);
@@ -694,15 +733,19 @@ __global__ void __launch_bounds__(LG_BLOCK) k_step(const KArgs A) {
 #pragma unroll 1
     for (int it = 0; it < P.decimation; it++) {
         if (NET) {
-            float perr[L];
 #pragma unroll
-            for (int j = 0; j < L; j++) perr[j] = act[j] * P.action_scale + tab[j * LG_JS + J_Q0] - q[j];
-            actuator_substep_mfma<L, LG_BLOCK>(LW, lds_lstm, perr, qd, tau);
+            for (int j = 0; j < L; j++) lds_x[j][lane] = make_float2(act[j] * P.action_scale + tab[j * LG_JS + J_Q0] - q[j], qd[j]);   // anymal.py:73-75
+            __syncthreads();                                   // actuator waves start on this sub-step
+            auto join = [&]() {
+                __syncthreads();                               // torques published
+#pragma unroll
+                for (int j = 0; j < L; j++) tau[j] = lds_tau[j][lane];
+            };
+            physics_substep<T, HF>(A, tab, k, root, q, qd, tau, base_mass, mu, Frep, Fbase, join);
         } else {
             pd_torques<L>(P, tab, act, q, qd, last_qd, tau);
+            physics_substep<T, HF>(A, tab, k, root, q, qd, tau, base_mass, mu, Frep, Fbase);
         }
-        LG_PROF(PF_TORQUE);
-        physics_substep<T, HF>(A, tab, k, root, q, qd, tau, base_mass, mu, Frep, Fbase);
     }
 
     // =====================  post_physics_step  (legged_robot.py:106-137)  =====================
@@ -763,6 +806,7 @@ __global__ void __launch_bounds__(LG_BLOCK) k_step(const KArgs A) {
     for (int j = 0; j < L; j++) bad |= !isfinite(q[j]) || !isfinite(qd[j]);
     bad = group_or<K>(bad);
     const bool reset = contact_term || time_out || bad;
+    if (NET) { lds_rst[lane] = reset ? 1 : 0; __syncthreads(); }      // actuator waves write their state back (zeroed on reset)
 
     // compute_reward :193-210 ; terms :872-969, cassie.py:43-46
     float last_act[L];
@@ -872,27 +916,6 @@ __global__ void __launch_bounds__(LG_BLOCK) k_step(const KArgs A) {
     write_observations<T>(A, e, k, live, step, root, q, qd, act, tab, blv, bav, pg, cmd, lds_h);
 
     // ---- write persistent state back (written once per env-step)
-    if (NET) {      // unit-split -> per-row 8-vectors (needs every lane of the wave), zeroed for reset envs
-#pragma unroll
-        for (int j = 0; j < L; j++) {
-            float *dst[4] = {B.sea_hidden_state + (size_t)(d0 + j) * 8, B.sea_cell_state + (size_t)(d0 + j) * 8,
-                             B.sea_hidden_state + (plane + d0 + j) * 8, B.sea_cell_state + (plane + d0 + j) * 8};
-#pragma unroll
-            for (int a = 0; a < 4; a++) {
-                float4 t0 = lds_lstm[j * 8 + 2 * a][threadIdx.x], t1 = lds_lstm[j * 8 + 2 * a + 1][threadIdx.x];
-                float g0[4] = {t0.x, t0.y, t0.z, t0.w}, g1[4] = {t1.x, t1.y, t1.z, t1.w}, u[8];
-                lstm_unsplit(g0, g1, u);
-                if (reset) {
-#pragma unroll
-                    for (int i = 0; i < 8; i++) u[i] = 0.0f;
-                }
-                if (live) {
-                    reinterpret_cast<float4 *>(dst[a])[0] = make_float4(u[0], u[1], u[2], u[3]);
-                    reinterpret_cast<float4 *>(dst[a])[1] = make_float4(u[4], u[5], u[6], u[7]);
-                }
-            }
-        }
-    }
     if (live) {
 #pragma unroll
         for (int j = 0; j < L; j++) {
@@ -924,7 +947,7 @@ __global__ void __launch_bounds__(LG_BLOCK) k_step(const KArgs A) {
     // Its inputs are device-scope atomics (performed at the memory side: no cache write-back / invalidate is needed, and an
     // agent-scope release fence per workgroup measured +6 us); the ticket is taken after this wave's own memory operations
     // have drained (s_waitcnt vmcnt(0)), and the finisher reads with device-scope (L1-bypassing) loads.
-    __shared__ int s_last;
+    }   // physics wave
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     LG_PROF(PF_POST);
     __syncthreads();
@@ -1392,8 +1415,8 @@ int lg_step(lg_sim *s, const float *actions, int64_t common_step_counter, void *
     const bool net = s->P.control_type == LG_CTRL_ACTUATOR_NET;
     if (s->kind == ROBOT_ANYMAL) {
         dim3 g(grid_for<AnymalTraits>(s->P.num_envs)), b(LG_BLOCK);
-        if (net && !hf) hipLaunchKernelGGL((k_step<AnymalTraits, true, false>), g, b, 0, st, a);
-        else if (net && hf) hipLaunchKernelGGL((k_step<AnymalTraits, true, true>), g, b, 0, st, a);
+        if (net && !hf) hipLaunchKernelGGL((k_step<AnymalTraits, true, false>), g, dim3((1 + AnymalTraits::L) * LG_BLOCK), 0, st, a);
+        else if (net && hf) hipLaunchKernelGGL((k_step<AnymalTraits, true, true>), g, dim3((1 + AnymalTraits::L) * LG_BLOCK), 0, st, a);
         else if (!net && !hf) hipLaunchKernelGGL((k_step<AnymalTraits, false, false>), g, b, 0, st, a);
         else hipLaunchKernelGGL((k_step<AnymalTraits, false, true>), g, b, 0, st, a);
     } else {
