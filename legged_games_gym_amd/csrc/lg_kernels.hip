@@ -1304,7 +1304,7 @@ int lg_policy_act(lg_policy *p, const float *obs, float *actions, float *mean, i
     a.obs = obs; a.actions = actions; a.mean = mean; a.std = p->d_std; a.step_counter = step_counter; a.step = step; a.seed = seed;
     a.num_envs = num_envs; a.num_obs = p->dims[0]; a.num_actions = p->dims[4]; a.deterministic = deterministic;
     for (int i = 0; i < 4; i++) { a.w[i] = p->d_w[i]; a.b[i] = p->d_b[i]; }
-    dim3 g((num_envs + 15) / 16), b(64);
+    dim3 g((num_envs + 15) / 16), b(64 * LG_POLICY_WAVES);
     hipStream_t st = (hipStream_t)stream;
     const int t0 = p->tiles[0], t1 = p->tiles[1], t2 = p->tiles[2], t3 = p->tiles[3];
     if (t0 == 3 && t1 == 8 && t2 == 4 && t3 == 2) hipLaunchKernelGGL((k_policy_act<3, 8, 4, 2>), g, b, 0, st, a);            // flat: 48-128-64-32

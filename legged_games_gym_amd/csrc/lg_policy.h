@@ -3,12 +3,14 @@
 // Stands in for rsl_rl ActorCritic.act() ([EXTERNAL]; dims from reference legged_robot_config.py:204-209 and
 // anymal_c_flat_config.py:62-65): a = actor(obs) + std * eps, actor = Linear/ELU x3 + Linear.
 //
-// One wave = 16 envs.  v_mfma_f32_16x16x4_f32 computes  D[out 16][env 16] += W[out][k 4] * X[k][env]:
+// One workgroup = 16 envs on LG_POLICY_WAVES waves (one per SIMD of the CU: a lone wave issues serially, so the layer's
+// output tiles are dealt round-robin to the waves and the activations are exchanged through LDS, one barrier per layer).
+// v_mfma_f32_16x16x4_f32 computes  D[out 16][env 16] += W[out][k 4] * X[k][env]:
 //   A operand (weights): lane l holds W[16*o + (l&15)][k_(l>>4)],   B operand (activations): lane l holds X[k_(l>>4)][env l&15],
 //   D: lane l holds rows 4*(l>>4)+r (r = 0..3) of column env l&15.
-// So register r of output tile t holds, on lane group g = l>>4, feature 16t + 4g + r of env l&15 -- which is exactly a
+// So the float4 a lane owns of output tile t (lane group g = l>>4) is features 16t + 4g + (0..3) of env l&15 -- exactly a
 // B operand if the next layer's K-steps are enumerated as (t, r) with k_g = 16t + 4g + r.  The host permutes the weight
-// columns accordingly (lg_policy_pack), hence activations never leave registers: no LDS, no transposes, no barriers.
+// columns accordingly (lg_policy_pack), so the LDS exchange is a plain [tile][lane] float4 array: no transposes.
 // Weights stream from L2 as one coalesced 256-B load per MFMA (the whole flat actor is 67 KB).
 #pragma once
 #include "lg_device.h"
@@ -19,22 +21,26 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 LG_DEV float elu1(float x) { return x > 0.0f ? x : (__builtin_amdgcn_exp2f(1.442695041f * x) - 1.0f); }
 
-// one layer: IN_T input tiles of 16 features (registers x[IN_T][4]) -> OUT_T output tiles
+#define LG_POLICY_WAVES 4
+// one layer: IN_T input tiles (LDS, [tile][lane] float4) -> OUT_T output tiles (LDS); wave w computes tiles w, w + NW, ...
 template <int IN_T, int OUT_T, bool ACT>
 LG_DEV void mlp_layer(const float *__restrict__ w /* [OUT_T][IN_T*4][64] */, const float *__restrict__ b /* [OUT_T][4][64] */,
-                      const float (&x)[IN_T][4], float (&y)[OUT_T][4], int lane) {
-#pragma unroll
-    for (int o = 0; o < OUT_T; o++) {
+                      const float4 (*xin)[64], float4 (*xout)[64], int wave, int lane) {
+#pragma unroll 1
+    for (int o = wave; o < OUT_T; o += LG_POLICY_WAVES) {
         f32x4 acc;
 #pragma unroll
         for (int r = 0; r < 4; r++) acc[r] = b[(o * 4 + r) * 64 + lane];
         const float *wo = w + (size_t)o * IN_T * 4 * 64 + lane;
 #pragma unroll
-        for (int t = 0; t < IN_T; t++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wo[(t * 4 + r) * 64], x[t][r], acc, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 4; r++) y[o][r] = ACT ? elu1(acc[r]) : acc[r];
+        for (int t = 0; t < IN_T; t++) {
+            const float4 xv = xin[t][lane];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wo[(t * 4 + 0) * 64], xv.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wo[(t * 4 + 1) * 64], xv.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wo[(t * 4 + 2) * 64], xv.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wo[(t * 4 + 3) * 64], xv.w, acc, 0, 0, 0);
+        }
+        xout[o][lane] = ACT ? make_float4(elu1(acc[0]), elu1(acc[1]), elu1(acc[2]), elu1(acc[3])) : make_float4(acc[0], acc[1], acc[2], acc[3]);
     }
 }
 
@@ -52,23 +58,32 @@ struct PolicyArgs {
 };
 
 template <int D0T, int D1T, int D2T, int D3T>     // layer widths in tiles of 16 (D0T = ceil(num_obs/16)); output = 1 tile
-__global__ void __launch_bounds__(64) k_policy_act(const PolicyArgs A) {
-    const int lane = threadIdx.x, g = lane >> 4;
+__global__ void __launch_bounds__(64 * LG_POLICY_WAVES) k_policy_act(const PolicyArgs A) {
+    constexpr int TA = D0T > D2T ? D0T : D2T, TB = D1T > D3T ? D1T : D3T;
+    __shared__ float4 xa[TA][64], xb[TB][64], xy[1][64];          // ping-pong activations: obs/x2 in xa, x1/x3 in xb
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4;
     int env = blockIdx.x * 16 + (lane & 15);
     const bool live = env < A.num_envs;
     if (!live) env = A.num_envs - 1;
-    // layer-0 B operands straight from global: k_g = 16t + 4g + r
-    float x0[D0T][4];
+    // layer-0 B operands from global: k_g = 16t + 4g + r
     const float *o = A.obs + (size_t)env * A.num_obs;
+    for (int t = wave; t < D0T; t += LG_POLICY_WAVES) {
+        float v[4];
 #pragma unroll
-    for (int t = 0; t < D0T; t++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) { int k = 16 * t + 4 * g + r; x0[t][r] = k < A.num_obs ? o[k] : 0.0f; }
-    float x1[D1T][4], x2[D2T][4], x3[D3T][4], y[1][4];
-    mlp_layer<D0T, D1T, true>(A.w[0], A.b[0], x0, x1, lane);
-    mlp_layer<D1T, D2T, true>(A.w[1], A.b[1], x1, x2, lane);
-    mlp_layer<D2T, D3T, true>(A.w[2], A.b[2], x2, x3, lane);
-    mlp_layer<D3T, 1, false>(A.w[3], A.b[3], x3, y, lane);
+        for (int r = 0; r < 4; r++) { int k = 16 * t + 4 * g + r; v[r] = k < A.num_obs ? o[k] : 0.0f; }
+        xa[t][lane] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    __syncthreads();
+    mlp_layer<D0T, D1T, true>(A.w[0], A.b[0], xa, xb, wave, lane);
+    __syncthreads();
+    mlp_layer<D1T, D2T, true>(A.w[1], A.b[1], xb, xa, wave, lane);
+    __syncthreads();
+    mlp_layer<D2T, D3T, true>(A.w[2], A.b[2], xa, xb, wave, lane);
+    __syncthreads();
+    if (wave != 0) return;
+    mlp_layer<D3T, 1, false>(A.w[3], A.b[3], xb, xy, 0, lane);
+    const float4 yv = xy[0][lane];                                 // written by this lane
+    const float y[1][4] = {{yv.x, yv.y, yv.z, yv.w}};
     // lane (env, g) now holds mean[4g + r]; sample a = mean + std * eps  (Philox -> Box-Muller)
     const int64_t step = A.step >= 0 ? A.step : (A.step_counter ? A.step_counter[0] + 1 : 0);
     float u[4];
