@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--policy", choices=["auto", "fused", "torch"], default="auto",
                     help="auto: fused MFMA actor kernel for narrow nets (hidden <= 128, the flat config), torch/hipBLASLt otherwise")
     ap.add_argument("--torch-policy", action="store_true", help="same as --policy torch")
+    ap.add_argument("--graph-steps", type=int, default=20, help="policy steps captured per HIP-graph replay (clamped to a divisor of --steps and --warmup)")
+    ap.add_argument("--no-fused-step", action="store_true", help="keep actor kernel and step kernel separate (lg_policy_act + lg_step)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one captured HIP graph per step")
     ap.add_argument("--event-steps", type=int, default=200, help="eager steps timed with HIP events for the roofline object")
     a = ap.parse_args()
@@ -95,17 +97,31 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    fused_step = False                                    # actor fused INTO the step kernel (lg_step_policy): flat actor only
+    G = 1
+    if not a.no_graph:
+        G = max(g for g in range(1, max(1, a.graph_steps) + 1) if a.steps % g == 0 and a.warmup % g == 0)
     with torch.inference_mode():
-        if a.no_graph:
+        if not use_torch and not a.no_fused_step:
+            try:
+                one_step = env.make_graphed_policy_step(fused, steps_per_replay=G) if not a.no_graph else (lambda: env.step_policy(fused))
+                if a.no_graph:
+                    one_step()
+                fused_step = True
+            except RuntimeError:
+                fused_step = False
+        if fused_step:
+            pass
+        elif a.no_graph:
             def one_step():
                 env.step(policy_act(env.obs_buf))             # the full VecEnv step (one lg_step call)
         else:
-            one_step = env.make_graphed_step(policy_act)      # policy forward + sampling + lg_step in ONE HIP graph
-        for _ in range(a.warmup):
+            one_step = env.make_graphed_step(policy_act, steps_per_replay=G)      # policy forward + sampling + lg_step in ONE HIP graph
+        for _ in range(a.warmup // G):
             one_step()
         sync()
         t0 = time.perf_counter()
-        for i in range(a.steps):
+        for i in range(a.steps // G):                      # exactly a.steps policy steps: G per graph replay
             one_step()
         sync()
         elapsed = time.perf_counter() - t0
@@ -114,10 +130,15 @@ def main():
         n_ev = max(1, min(a.event_steps, a.steps))
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
         for s_, e_ in ev:
-            actions = policy_act(env.obs_buf)
-            s_.record()
-            env.step(actions)
-            e_.record()
+            if fused_step:
+                s_.record()
+                env.step_policy(fused)
+                e_.record()
+            else:
+                actions = policy_act(env.obs_buf)
+                s_.record()
+                env.step(actions)
+                e_.record()
         torch.cuda.synchronize()
     finite = bool(torch.isfinite(env.obs_buf).all()) and bool(torch.isfinite(env.root_states).all())
     kern_ms = sum(s_.elapsed_time(e_) for s_, e_ in ev) / n_ev
@@ -149,10 +170,10 @@ def main():
                                    "fixed command (0.5,0,0), obs noise + friction/mass randomisation + pushes on",
                        "envs_per_gpu": a.num_envs, "decimation": int(env.cfg.control.decimation), "sim_dt": float(env.sim_params.dt),
                        "parallelism": f"env-sharded x{world}", "state_finite": finite,
-                       "launch": "eager" if a.no_graph else "one captured HIP graph per policy step (policy + lg_step)",
-                       "policy": "torch ops (hipBLASLt)" if a.torch_policy else "fused MFMA actor kernel (lg_policy_act, v_mfma_f32_16x16x4_f32)"},
+                       "launch": ("eager" if a.no_graph else f"HIP graph of {G} policy steps per replay") + (": ONE kernel, actor fused into the step (lg_step_policy)" if fused_step else " (policy + lg_step)"),
+                       "policy": "torch ops (hipBLASLt)" if a.torch_policy else ("MFMA actor inside k_step (v_mfma_f32_16x16x4_f32, 4 waves)" if fused_step else "fused MFMA actor kernel (lg_policy_act, v_mfma_f32_16x16x4_f32)")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": "profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, 2*FETCH+WRITE KiB)" if traffic else None, "kernel": "k_step<AnymalTraits,NET,plane>" if a.task != "cassie" else "k_step<CassieTraits>",
+                         "traffic": traffic, "traffic_source": "profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, 2*FETCH+WRITE KiB)" if traffic else None, "kernel": ("k_step<AnymalTraits,NET,plane,POL> (actor + step)" if fused_step else "k_step<AnymalTraits,NET,plane>") if a.task != "cassie" else "k_step<CassieTraits>",
                          "kernel_ms": kern_ms, "kernel_ms_method": f"HIP events around {n_ev} eager lg_step launches (k_step + k_extras) right after the timed region",
                          "algorithmic_bytes_per_env_step": bpe,
                          "note": "fused step is VALU/latency-bound at 4096 envs (256 waves on 1024 SIMDs); see DESIGN.md"},

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LG_ABI_VERSION        8
+#define LG_ABI_VERSION        9
 
 #define LG_MAX_LIMBS          4
 #define LG_MAX_CHAIN          6
@@ -203,6 +203,15 @@ void lg_policy_destroy(lg_policy *p);
  * (>= 0) or, when -1, (*step_counter + 1) is read on the device (graph replay).  deterministic != 0 returns the mean. */
 int  lg_policy_act(lg_policy *p, const float *obs, float *actions, float *mean, int32_t num_envs, uint64_t seed,
                    int64_t step, const int64_t *step_counter, int32_t deterministic, void *stream);
+
+/* Fused rollout step: actions = actor(obs) + std * eps (as lg_policy_act, same noise stream keyed by the step counter)
+ * immediately followed by lg_step on those actions, in ONE launch.  `obs` is the observation tensor of the previous step
+ * (it may be the sim's own obs output buffer: a workgroup reads only its envs' rows, and before it rewrites them),
+ * `actions` / `mean` receive what rsl_rl's storage needs.
+ * Compiled for the flat actor (48-128-64-32) on the quadruped actuator-net plane kernel; other combinations return -4 and
+ * the caller uses lg_policy_act + lg_step (reference: ActorCritic.act + LeggedRobot.step, legged_robot.py:80-104). */
+int  lg_step_policy(lg_sim *sim, lg_policy *p, const float *obs, float *actions, float *mean, uint64_t seed,
+                    int32_t deterministic, int64_t common_step_counter, void *stream);
 
 const char *lg_last_error(void);
 int  lg_abi_version(void);

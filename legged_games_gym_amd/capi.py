@@ -16,7 +16,7 @@ from typing import Dict, Optional
 
 import numpy as np
 
-LG_ABI_VERSION = 8
+LG_ABI_VERSION = 9
 LG_MAX_LIMBS, LG_MAX_CHAIN, LG_MAX_DOF = 4, 6, 12
 LG_MAX_LIMB_POINTS, LG_MAX_BASE_POINTS, LG_MAX_BODIES = 8, 4, 20
 LG_MAX_HEIGHT_POINTS, LG_ACTUATOR_FLOATS = 192, 972
@@ -216,6 +216,8 @@ def bind_prototypes(lib, prefix: str):
         lib.lg_policy_destroy.argtypes, lib.lg_policy_destroy.restype = [vp], None
         lib.lg_policy_act.argtypes = [vp, vp, vp, vp, i32, u64, i64, vp, i32, vp]
         lib.lg_policy_act.restype = C.c_int
+        lib.lg_step_policy.argtypes = [vp, vp, vp, vp, vp, u64, i32, i64, vp]
+        lib.lg_step_policy.restype = C.c_int
     for name, (args, res) in sig.items():
         fn = getattr(lib, prefix + name)
         fn.argtypes, fn.restype = args, res
@@ -228,7 +230,8 @@ def bind_prototypes(lib, prefix: str):
 
 EXPORTED_SYMBOLS = ["lg_create", "lg_destroy", "lg_bind", "lg_step", "lg_reset_idx", "lg_actuator_forward",
                     "lg_physics_substep", "lg_compute_observations_only", "lg_set_params", "lg_last_error",
-                    "lg_abi_version", "lg_sizeof", "lg_set_obs_buffer", "lg_policy_create", "lg_policy_destroy", "lg_policy_act"]
+                    "lg_abi_version", "lg_sizeof", "lg_set_obs_buffer", "lg_policy_create", "lg_policy_destroy", "lg_policy_act",
+                    "lg_step_policy"]
 
 
 def load_library():
@@ -282,6 +285,11 @@ class Sim:
 
     def step(self, actions_ptr: int, common_step_counter: int, stream: int = 0):
         self._check(self._fn("step")(self.handle, actions_ptr, int(common_step_counter), stream))
+
+    def step_policy(self, policy_handle, obs_ptr: int, actions_ptr: int, mean_ptr, seed: int, deterministic: bool,
+                    common_step_counter: int, stream: int = 0):
+        self._check(self.lib.lg_step_policy(self.handle, policy_handle, obs_ptr, actions_ptr, mean_ptr, int(seed), int(bool(deterministic)),
+                                            int(common_step_counter), stream))
 
     def reset_idx(self, ids_ptr: int, count: int, common_step_counter: int, stream: int = 0):
         self._check(self._fn("reset_idx")(self.handle, ids_ptr, int(count), int(common_step_counter), stream))

@@ -56,6 +56,7 @@ struct KArgs {                 // passed by value: lives in the kernarg segment 
     uint32_t   penalised_mask, termination_mask;
     unsigned int *done_counter;   // workgroup ticket of k_step (zeroed at create, self-resetting)
     int64_t    step;
+    PolicyArgs pol;               // fused rollout step (k_step<..., POL = true>): the actor that produces this step's actions
     unsigned long long *prof;     // LG_PROFILE builds only: [LG_NPROF] cycle accumulators (tools/profile_sections.py)
 };
 
@@ -670,8 +671,11 @@ template <class T> struct ActuatorWave {
     }
 };
 
-template <class T, bool NET, bool HF>
+// POL: the flat actor (48-128-64-32) runs first on the same four waves (lg_policy.h) and hands the sampled actions over
+// in LDS -- one launch per rollout step instead of policy kernel + step kernel.
+template <class T, bool NET, bool HF, bool POL = false>
 __global__ void __launch_bounds__(NET ? (1 + T::L) * LG_BLOCK : LG_BLOCK) k_step(const KArgs A) {
+    static_assert(!POL || (NET && (1 + T::L) == LG_POLICY_WAVES && T::K * T::L <= 16), "fused policy needs the four-wave actuator-net kernel");
     constexpr int K = T::K, L = T::L, ND = K * L, NREP = T::NREP;
     const lg_params &P = A.P;
     const lg_buffers &B = A.B;
@@ -681,6 +685,8 @@ __global__ void __launch_bounds__(NET ? (1 + T::L) * LG_BLOCK : LG_BLOCK) k_step
     __shared__ float lds_tau[NET ? L : 1][LG_BLOCK];            // actuator torques of the sub-step
     __shared__ int lds_rst[LG_BLOCK];                           // reset flag of the lane's env, for the actuator waves' write-back
     __shared__ int s_last;
+    __shared__ float4 pol_xa[POL ? 4 : 1][64], pol_xb[POL ? 8 : 1][64], pol_xy[1][64];
+    __shared__ float lds_act[POL ? 16 : 1][16];                 // sampled actions [action][env in block]
     LG_PROF_BEGIN();
     stage_limb_table<T>(A, lds_tab);
 
@@ -695,6 +701,10 @@ __global__ void __launch_bounds__(NET ? (1 + T::L) * LG_BLOCK : LG_BLOCK) k_step
     const int d0 = e * ND + k * L;                                // first dof of this lane
     const int64_t step = A.step >= 0 ? A.step : B.step_counter[0] + 1;   // -1: self-advancing (HIP-graph replay)
 
+    if (POL) {
+        policy_forward<3, 8, 4, 2>(A.pol, pol_xa, pol_xb, pol_xy, blockIdx.x, wave, lane, step, lds_act);
+        __syncthreads();
+    }
     if (NET && wave > 0) {
         ActuatorWave<T>::run(A, wave - 1, lane, d0, live, lds_x, lds_tau, lds_rst);
     } else {
@@ -706,7 +716,7 @@ __global__ void __launch_bounds__(NET ? (1 + T::L) * LG_BLOCK : LG_BLOCK) k_step
     for (int j = 0; j < L; j++) {
         float2 s = reinterpret_cast<const float2 *>(B.dof_state)[d0 + j];
         q[j] = s.x; qd[j] = s.y;
-        float a = A.actions_in[d0 + j];
+        float a = POL ? lds_act[k * L + j][lane / K] : A.actions_in[d0 + j];
         act[j] = fminf(fmaxf(a, -P.clip_actions), P.clip_actions);       // :86-87
         tau[j] = 0.0f;
     }
@@ -1230,7 +1240,7 @@ static int upload_tables(lg_sim *s) {
 
 static void fill_args(const lg_sim *s, KArgs &a, int64_t step) {
     a.P = s->P; a.B = s->B; a.base = s->base; a.limb_table = s->d_limb_table; a.weights = s->d_weights;
-    a.actions_in = nullptr; a.env_ids = nullptr; a.count = 0; a.step = step;
+    a.actions_in = nullptr; a.env_ids = nullptr; a.count = 0; a.step = step; memset(&a.pol, 0, sizeof a.pol);
     a.penalised_mask = s->M.penalised_mask; a.termination_mask = s->M.termination_mask; a.done_counter = s->d_done; a.prof = s->d_prof;
 }
 template <class T> static int grid_for(int n_env_like) { return (n_env_like * T::K + LG_BLOCK - 1) / LG_BLOCK; }
@@ -1296,14 +1306,19 @@ void lg_policy_destroy(lg_policy *p) {
     delete p;
 }
 
+static void fill_policy_args(const lg_policy *p, PolicyArgs &a, const float *obs, float *actions, float *mean, int32_t num_envs, uint64_t seed,
+                             int64_t step, const int64_t *step_counter, int32_t deterministic) {
+    a.obs = obs; a.actions = actions; a.mean = mean; a.std = p->d_std; a.step_counter = step_counter; a.step = step; a.seed = seed;
+    a.num_envs = num_envs; a.num_obs = p->dims[0]; a.num_actions = p->dims[4]; a.deterministic = deterministic;
+    for (int i = 0; i < 4; i++) { a.w[i] = p->d_w[i]; a.b[i] = p->d_b[i]; }
+}
+
 int lg_policy_act(lg_policy *p, const float *obs, float *actions, float *mean, int32_t num_envs, uint64_t seed, int64_t step,
                   const int64_t *step_counter, int32_t deterministic, void *stream) {
     if (!p || !obs || !actions) return fail(-1, "null argument");
     if (num_envs <= 0) return 0;
     PolicyArgs a;
-    a.obs = obs; a.actions = actions; a.mean = mean; a.std = p->d_std; a.step_counter = step_counter; a.step = step; a.seed = seed;
-    a.num_envs = num_envs; a.num_obs = p->dims[0]; a.num_actions = p->dims[4]; a.deterministic = deterministic;
-    for (int i = 0; i < 4; i++) { a.w[i] = p->d_w[i]; a.b[i] = p->d_b[i]; }
+    fill_policy_args(p, a, obs, actions, mean, num_envs, seed, step, step_counter, deterministic);
     dim3 g((num_envs + 15) / 16), b(64 * LG_POLICY_WAVES);
     hipStream_t st = (hipStream_t)stream;
     const int t0 = p->tiles[0], t1 = p->tiles[1], t2 = p->tiles[2], t3 = p->tiles[3];
@@ -1424,6 +1439,23 @@ int lg_step(lg_sim *s, const float *actions, int64_t common_step_counter, void *
         if (!hf) hipLaunchKernelGGL((k_step<CassieTraits, false, false>), g, b, 0, st, a);
         else hipLaunchKernelGGL((k_step<CassieTraits, false, true>), g, b, 0, st, a);
     }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int lg_step_policy(lg_sim *s, lg_policy *p, const float *obs, float *actions, float *mean, uint64_t seed, int32_t deterministic,
+                   int64_t common_step_counter, void *stream) {
+    if (!s || !s->bound) return fail(-8, "lg_bind has not been called");
+    if (!p || !obs || !actions) return fail(-1, "null argument");
+    if (common_step_counter < 0 && !s->B.step_counter) return fail(-9, "common_step_counter = -1 needs a step_counter buffer");
+    const bool flat_actor = p->tiles[0] == 3 && p->tiles[1] == 8 && p->tiles[2] == 4 && p->tiles[3] == 2 && p->dims[4] == s->M.num_limbs * s->M.chain_len;
+    if (!(s->kind == ROBOT_ANYMAL && s->P.control_type == LG_CTRL_ACTUATOR_NET && s->P.terrain_type != LG_TERRAIN_HEIGHTFIELD && flat_actor
+          && p->dims[0] == s->P.num_obs))
+        return fail(-4, "the fused policy step is compiled for the 48-128-64-32 actor on the quadruped actuator-net plane kernel; use lg_policy_act + lg_step");
+    KArgs a; fill_args(s, a, common_step_counter); a.actions_in = nullptr;
+    fill_policy_args(p, a.pol, obs, actions, mean, s->P.num_envs, seed, common_step_counter, s->B.step_counter, deterministic);
+    hipLaunchKernelGGL((k_step<AnymalTraits, true, false, true>), dim3(grid_for<AnymalTraits>(s->P.num_envs)), dim3((1 + AnymalTraits::L) * LG_BLOCK),
+                       0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }

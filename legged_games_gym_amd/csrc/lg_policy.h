@@ -57,12 +57,15 @@ struct PolicyArgs {
     int32_t num_envs, num_obs, num_actions, deterministic;
 };
 
-template <int D0T, int D1T, int D2T, int D3T>     // layer widths in tiles of 16 (D0T = ceil(num_obs/16)); output = 1 tile
-__global__ void __launch_bounds__(64 * LG_POLICY_WAVES) k_policy_act(const PolicyArgs A) {
-    constexpr int TA = D0T > D2T ? D0T : D2T, TB = D1T > D3T ? D1T : D3T;
-    __shared__ float4 xa[TA][64], xb[TB][64], xy[1][64];          // ping-pong activations: obs/x2 in xa, x1/x3 in xb
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4;
-    int env = blockIdx.x * 16 + (lane & 15);
+// Actor forward + sampling for the 16 envs of workgroup `block`; must be called by all LG_POLICY_WAVES waves of the
+// workgroup (contains barriers).  Wave 0 samples and writes actions / mean to global memory and, if `lds_act` is given,
+// publishes the sampled actions as lds_act[action][env-in-block] for a consumer in the same workgroup (k_step's fused mode;
+// the caller places the barrier).  Layer widths in tiles of 16 (D0T = ceil(num_obs/16)); the output layer is one tile.
+template <int D0T, int D1T, int D2T, int D3T>
+LG_DEV void policy_forward(const PolicyArgs &A, float4 (*xa)[64], float4 (*xb)[64], float4 (*xy)[64], int block, int wave, int lane,
+                           int64_t step, float (*lds_act)[16]) {
+    const int g = lane >> 4;
+    int env = block * 16 + (lane & 15);
     const bool live = env < A.num_envs;
     if (!live) env = A.num_envs - 1;
     // layer-0 B operands from global: k_g = 16t + 4g + r
@@ -83,9 +86,8 @@ __global__ void __launch_bounds__(64 * LG_POLICY_WAVES) k_policy_act(const Polic
     if (wave != 0) return;
     mlp_layer<D3T, 1, false>(A.w[3], A.b[3], xb, xy, 0, lane);
     const float4 yv = xy[0][lane];                                 // written by this lane
-    const float y[1][4] = {{yv.x, yv.y, yv.z, yv.w}};
+    const float y[4] = {yv.x, yv.y, yv.z, yv.w};
     // lane (env, g) now holds mean[4g + r]; sample a = mean + std * eps  (Philox -> Box-Muller)
-    const int64_t step = A.step >= 0 ? A.step : (A.step_counter ? A.step_counter[0] + 1 : 0);
     float u[4];
     rand4(A.seed ^ 0x9E3779B97F4A7C15ull, env, step, 100 + g, 0, u);
     float rad0 = sqrtf(-2.0f * __logf(fmaxf(u[0], 1e-12f))), rad1 = sqrtf(-2.0f * __logf(fmaxf(u[2], 1e-12f)));
@@ -93,17 +95,26 @@ __global__ void __launch_bounds__(64 * LG_POLICY_WAVES) k_policy_act(const Polic
     __sincosf(6.2831853f * u[1], &s0, &c0);
     __sincosf(6.2831853f * u[3], &s1, &c1);
     float eps[4] = {rad0 * c0, rad0 * s0, rad1 * c1, rad1 * s1};
-    if (live) {
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            int a = 4 * g + r;
-            if (a < A.num_actions) {
-                float m = y[0][r];
+    for (int r = 0; r < 4; r++) {
+        int a = 4 * g + r;
+        if (a < A.num_actions) {
+            float m = y[r], act = A.deterministic ? m : m + A.std[a] * eps[r];
+            if (lds_act) lds_act[a][lane & 15] = act;
+            if (live) {
                 if (A.mean) A.mean[(size_t)env * A.num_actions + a] = m;
-                A.actions[(size_t)env * A.num_actions + a] = A.deterministic ? m : m + A.std[a] * eps[r];
+                A.actions[(size_t)env * A.num_actions + a] = act;
             }
         }
     }
+}
+
+template <int D0T, int D1T, int D2T, int D3T>
+__global__ void __launch_bounds__(64 * LG_POLICY_WAVES) k_policy_act(const PolicyArgs A) {
+    constexpr int TA = D0T > D2T ? D0T : D2T, TB = D1T > D3T ? D1T : D3T;
+    __shared__ float4 xa[TA][64], xb[TB][64], xy[1][64];          // ping-pong activations: obs/x2 in xa, x1/x3 in xb
+    const int64_t step = A.step >= 0 ? A.step : (A.step_counter ? A.step_counter[0] + 1 : 0);
+    policy_forward<D0T, D1T, D2T, D3T>(A, xa, xb, xy, blockIdx.x, threadIdx.x >> 6, threadIdx.x & 63, step, nullptr);
 }
 
 }  // namespace lg

@@ -67,6 +67,17 @@ class DeviceSim:
         self._keep = actions
         self.sim.step(actions.data_ptr(), counter, self._stream())
 
+    def step_policy(self, fused_actor, obs: torch.Tensor, counter: int, deterministic: bool = False, want_mean: bool = True):
+        """``actions = actor(obs) + std * eps`` and the env step in ONE launch (``lg_step_policy``); returns the
+        (actions, mean) tensors owned by ``fused_actor``.  Raises if the sim / actor pair is not a compiled fused shape."""
+        if obs.dtype != torch.float32 or not obs.is_contiguous() or obs.device != self.device:
+            raise ValueError("obs must be a contiguous float32 tensor on the sim device")
+        # obs may be the sim's own output buffer: a workgroup reads only its 16 envs' rows, and before it writes them
+        actions, mean = fused_actor.output_buffers(self.params.num_envs)
+        self.sim.step_policy(fused_actor.handle, obs.data_ptr(), actions.data_ptr(), mean.data_ptr() if want_mean else None,
+                             fused_actor.seed, deterministic, counter, self._stream())
+        return actions, mean
+
     def reset_idx(self, env_ids: torch.Tensor, counter: int):
         ids = env_ids.to(device=self.device, dtype=torch.int32).contiguous()
         if ids.numel() == 0:

@@ -58,6 +58,25 @@ class LeggedRobot(BaseTask):
         self._sim.step(actions, -1 if self._capturing else self.common_step_counter)
         return self.obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf, self.extras
 
+    def step_policy(self, fused_actor, deterministic=False):
+        """Rollout step with the actor fused in: ``actions = fused_actor(obs_buf)`` and ``step(actions)`` as ONE launch
+        (``lg_step_policy``).  Returns ``(actions, mean), (obs, privileged_obs, rew, dones, extras)``.  Only for the
+        compiled fused shape (flat ANYmal actor on the plane); raises RuntimeError otherwise -- use ``step``."""
+        self.common_step_counter += 1
+        prev_obs = self.obs_buf
+        self._obs_flip ^= 1
+        self.obs_buf = self._obs_pair[self._obs_flip]
+        self._sim.set_obs_output(self.obs_buf)
+        try:
+            am = self._sim.step_policy(fused_actor, prev_obs, -1 if self._capturing else self.common_step_counter, deterministic)
+        except Exception:
+            self.common_step_counter -= 1
+            self._obs_flip ^= 1
+            self.obs_buf = prev_obs
+            self._sim.set_obs_output(self.obs_buf)
+            raise
+        return am, (self.obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf, self.extras)
+
     def post_physics_step(self):
         raise RuntimeError("post_physics_step is fused into lg_step; call step()")
 
@@ -70,7 +89,7 @@ class LeggedRobot(BaseTask):
         self._capturing = False
         self.common_step_counter -= steps_captured      # capture does not execute; replays are accounted by the caller
 
-    def make_graphed_step(self, policy_act, warmup=3):
+    def make_graphed_step(self, policy_act, warmup=3, steps_per_replay=1):
         """Capture ``actions = policy_act(obs_buf); step(actions)`` into one HIP graph and return a
         zero-argument callable that replays it (launch-bound inner loop -> one hipGraphLaunch).
         The step counter lives on the device while replaying (``lg_step(..., -1)``), the host copy is
@@ -87,12 +106,38 @@ class LeggedRobot(BaseTask):
         torch.cuda.current_stream(self.device).wait_stream(side)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            sim.step(policy_act(self.obs_buf), -1)
+            for _ in range(steps_per_replay):                # several policy steps per hipGraphLaunch: no host in between
+                sim.step(policy_act(self.obs_buf), -1)
         self._step_graph = graph
 
         def replay():
             graph.replay()
-            self.common_step_counter += 1
+            self.common_step_counter += steps_per_replay
+            return self.obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf, self.extras
+        return replay
+
+    def make_graphed_policy_step(self, fused_actor, warmup=3, steps_per_replay=1):
+        """Like ``make_graphed_step`` with the actor fused into the step kernel: the graph is ONE ``lg_step_policy`` launch
+        (obs_buf -> actions -> next obs_buf, in place).  Raises RuntimeError when the sim / actor pair has no fused kernel."""
+        sim = self._sim
+        sim.set_obs_output(self.obs_buf)
+        sim.buf["step_counter"].fill_(self.common_step_counter)
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                sim.step_policy(fused_actor, self.obs_buf, -1)
+                self.common_step_counter += 1
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for _ in range(steps_per_replay):
+                sim.step_policy(fused_actor, self.obs_buf, -1)
+        self._step_graph = graph
+
+        def replay():
+            graph.replay()
+            self.common_step_counter += steps_per_replay
             return self.obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf, self.extras
         return replay
 

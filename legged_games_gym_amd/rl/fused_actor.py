@@ -52,12 +52,16 @@ class FusedActor:
             raise RuntimeError(f"lg_policy_create failed ({rc}): {self.lib.lg_last_error().decode()}")
         self.num_actions = lin[3].out_features
 
+    def output_buffers(self, n):
+        """(actions, mean) tensors the kernels write into (re-used between calls; clone to keep a value)."""
+        if self._out is None or self._out[0].shape[0] != n:
+            self._out = (torch.empty(n, self.num_actions, device=self.device), torch.empty(n, self.num_actions, device=self.device))
+        return self._out
+
     def _call(self, obs, deterministic, want_mean):
         obs = obs if (obs.dtype == torch.float32 and obs.is_contiguous()) else obs.float().contiguous()
         n = obs.shape[0]
-        if self._out is None or self._out[0].shape[0] != n:
-            self._out = (torch.empty(n, self.num_actions, device=self.device), torch.empty(n, self.num_actions, device=self.device))
-        actions, mean = self._out
+        actions, mean = self.output_buffers(n)
         if self.step_counter is not None:
             step, ctr = -1, self.step_counter.data_ptr()
         else:

@@ -118,6 +118,38 @@ def test_fused_actor_matches_torch_forward():
         assert torch.allclose(fa.act_inference(obs), want2, atol=2e-5 * max(1.0, float(want2.abs().max())))
 
 
+def test_fused_policy_step_equals_actor_kernel_plus_step():
+    """lg_step_policy (actor inside the step kernel) == lg_policy_act followed by lg_step on the same state and noise stream."""
+    from legged_games_gym_amd.rl import ActorCritic, FusedActor
+    from legged_games_gym_amd.utils.helpers import class_to_dict
+    outs = []
+    for fused_step in (False, True):
+        env, cfg = _env("anymal_c_flat", 200)                  # 200 envs: a partial last workgroup
+        from legged_games_gym_amd.envs import task_registry
+        _, train_cfg = task_registry.get_cfgs("anymal_c_flat")
+        torch.manual_seed(3)
+        ac = ActorCritic(env.num_obs, env.num_obs, env.num_actions, **class_to_dict(train_cfg.policy)).to("cuda")
+        actor = FusedActor(ac, "cuda:0", seed=11)
+        obs, _ = env.reset()
+        rec = []
+        for t in range(6):
+            if fused_step:
+                (act, mean), (obs, _, rew, dones, _) = env.step_policy(actor)
+                act, mean = act.clone(), mean.clone()
+            else:
+                actor._host_step = env.common_step_counter      # same Philox step as the fused kernel uses (counter + 1)
+                act, mean = (x.clone() for x in actor.act_with_mean(obs))
+                obs, _, rew, dones, _ = env.step(act)
+            rec.append((act, mean, obs.clone(), rew.clone(), dones.clone(), env.dof_pos.clone()))
+        outs.append(rec)
+    for a, b in zip(*outs):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y) if x.dtype == torch.bool else float((x - y).abs().max()) == 0.0
+    with pytest.raises(RuntimeError, match="fused policy step"):
+        env2, _ = _env("cassie", 16)
+        env2.step_policy(actor)
+
+
 def test_step_returns_a_fresh_observation_tensor_like_the_reference():
     """legged_robot.py:215 re-creates obs_buf each step; rsl_rl's PPO.act holds the previous tensor by reference until
     process_env_step.  The obs returned by step t must therefore survive step t+1 untouched."""
