@@ -125,23 +125,25 @@ def main():
             one_step()
         sync()
         elapsed = time.perf_counter() - t0
-        # roofline: duration of the fused step kernel from HIP events recorded on the launch stream around eager
-        # lg_step launches of the SAME rollout, directly after the timed region (a graph replay cannot host events)
-        n_ev = max(1, min(a.event_steps, a.steps))
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
+        # roofline: duration of the step kernel from HIP events (recorded on the launch stream) around replays of a HIP graph
+        # that holds ONLY that kernel, G launches back to back, directly after the timed region.  (Events around eager
+        # launches measure the host's enqueue latency instead: the kernel is shorter than one Python call.)
+        if fused_step and not a.no_graph:
+            kernel_replay, KG = one_step, G                      # the timed graph already is G x k_step<..., POL>
+        else:
+            KG = 20
+            fixed_actions = (policy_act(env.obs_buf) if not fused_step else fused.act(env.obs_buf)).clone()
+            kernel_replay = env.make_graphed_step(lambda _obs: fixed_actions, steps_per_replay=KG)   # G x lg_step, nothing else
+        n_rep = max(1, min(a.event_steps, a.steps) // KG)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_rep)]
+        kernel_replay()
         for s_, e_ in ev:
-            if fused_step:
-                s_.record()
-                env.step_policy(fused)
-                e_.record()
-            else:
-                actions = policy_act(env.obs_buf)
-                s_.record()
-                env.step(actions)
-                e_.record()
+            s_.record()
+            kernel_replay()
+            e_.record()
         torch.cuda.synchronize()
     finite = bool(torch.isfinite(env.obs_buf).all()) and bool(torch.isfinite(env.root_states).all())
-    kern_ms = sum(s_.elapsed_time(e_) for s_, e_ in ev) / n_ev
+    kern_ms = sum(s_.elapsed_time(e_) for s_, e_ in ev) / (n_rep * KG)
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev if (world == 1 or dist.get_backend() == "nccl") else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -174,7 +176,7 @@ def main():
                        "policy": "torch ops (hipBLASLt)" if a.torch_policy else ("MFMA actor inside k_step (v_mfma_f32_16x16x4_f32, 4 waves)" if fused_step else "fused MFMA actor kernel (lg_policy_act, v_mfma_f32_16x16x4_f32)")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": "profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, 2*FETCH+WRITE KiB)" if traffic else None, "kernel": ("k_step<AnymalTraits,NET,plane,POL> (actor + step)" if fused_step else "k_step<AnymalTraits,NET,plane>") if a.task != "cassie" else "k_step<CassieTraits>",
-                         "kernel_ms": kern_ms, "kernel_ms_method": f"HIP events around {n_ev} eager lg_step launches (k_step + k_extras) right after the timed region",
+                         "kernel_ms": kern_ms, "kernel_ms_method": f"HIP events around {n_rep} replays of a HIP graph of {KG} back-to-back launches of the step kernel alone, right after the timed region (per-launch average, includes ~1 us launch gap)",
                          "algorithmic_bytes_per_env_step": bpe,
                          "note": "fused step is VALU/latency-bound at 4096 envs (256 waves on 1024 SIMDs); see DESIGN.md"},
         }

@@ -428,59 +428,84 @@ LG_DEV float sample_height(const KArgs &A, const float *root, const float *qy, i
     return (float)h * P.hf_vertical_scale;
 }
 
-// Heights of this lane's chunks c = k, k+K, ... (4 points each), NB chunks per batch so 3*4*NB height-field gathers are in
-// flight before the first one is consumed (the samples are L2-resident but ~1 us away for a lone wave).  Results go to
-// measured_heights (the reference's buffer) and, as one float4 per chunk, to this lane's LDS column for the observation.
-#define LG_HSLOTS(K) (((LG_MAX_HEIGHT_POINTS + 3) / 4 + (K) - 1) / (K))
-template <class T, bool HF>
-LG_DEV float sample_heights(const KArgs &A, int e, int k, bool live, const float *root, float4 (*lds_h)[LG_BLOCK]) {
-    constexpr int K = T::K, NB = 4;
-    const lg_params &P = A.P;
-    float qy[4] = {0, 0, root[5], root[6]};
-    float nrm = fmaxf(sqrtf(qy[2] * qy[2] + qy[3] * qy[3]), 1e-9f);
-    qy[2] /= nrm; qy[3] /= nrm;
-    float *mh = A.B.measured_heights + (size_t)e * P.num_height_points;
-    const int np = P.num_height_points, nchunk = (np + 3) >> 2;
-    const int16_t *H = A.B.height_samples;
-    float hsum = 0.0f;
-    int slot = 0;
-    for (int c0 = k; c0 < nchunk; c0 += K * NB, slot += NB) {
-        int16_t s0[NB][4], s1[NB][4], s2[NB][4];
+// _get_heights (:831-869) and the height part of compute_observations (:224-226) for the fused step, spread over ALL waves
+// of the workgroup: an env's chunks (4 points = one Philox block each) are dealt to K * LG_STEP_WAVES "virtual lanes";
+// thread (wave, lane = (env, limb k)) is virtual lane k + K * wave and keeps its chunks' heights in registers between
+// sampling (before the reset decision) and the observation (after it, Q7).  All 3*4*NCH gathers are issued before the
+// first one is consumed (the samples are L2-resident but ~1 us away for a lone wave).
+#define LG_STEP_WAVES 4
+template <class T> struct HeightCrew {
+    static constexpr int NV = T::K * LG_STEP_WAVES;
+    static constexpr int NCH = ((LG_MAX_HEIGHT_POINTS + 3) / 4 + NV - 1) / NV;     // chunks per thread: 3 (K = 4) / 6 (K = 2)
+    float h[NCH][4];
+
+    template <bool HF>
+    LG_DEV float sample(const KArgs &A, int e, int sub, bool live, float x, float y, float z, float q5, float q6) {
+        const lg_params &P = A.P;
+        float qy[4] = {0, 0, q5, q6};
+        float nrm = fmaxf(sqrtf(qy[2] * qy[2] + qy[3] * qy[3]), 1e-9f);
+        qy[2] /= nrm; qy[3] /= nrm;
+        float *mh = A.B.measured_heights + (size_t)e * P.num_height_points;
+        const int np = P.num_height_points;
+        const int16_t *H = A.B.height_samples;
+        int16_t s0[NCH][4], s1[NCH][4], s2[NCH][4];
         if (HF) {
 #pragma unroll
-            for (int b = 0; b < NB; b++)
+            for (int b = 0; b < NCH; b++)
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
-                    int i = min(4 * (c0 + b * K) + t, np - 1);                     // clamped: the tail re-reads a valid point
+                    int i = min(4 * (sub + b * NV) + t, np - 1);                   // clamped: the tail re-reads a valid point
                     V3 p = quat_apply(qy, v3(P.height_points[i][0], P.height_points[i][1], 0.0f));
-                    float px = p.x + root[0] + P.hf_border, py = p.y + root[1] + P.hf_border;
+                    float px = p.x + x + P.hf_border, py = p.y + y + P.hf_border;
                     int ix = (int)(px / P.hf_horizontal_scale), iy = (int)(py / P.hf_horizontal_scale);   // .long(): truncation; int32 saturates, then clamps
                     ix = min(max(ix, 0), P.hf_rows - 2); iy = min(max(iy, 0), P.hf_cols - 2);
-                    const int16_t *hp = H + ix * P.hf_cols + iy;                 // rows x cols < 2^31 (checked at bind)
+                    const int16_t *hp = H + ix * P.hf_cols + iy;                   // rows x cols < 2^31 (checked at bind)
                     s0[b][t] = hp[0]; s1[b][t] = hp[P.hf_cols]; s2[b][t] = hp[1];
                 }
         }
+        float hsum = 0.0f;
 #pragma unroll
-        for (int b = 0; b < NB; b++) {
-            const int c = c0 + b * K;
-            float hh[4];
+        for (int b = 0; b < NCH; b++)
 #pragma unroll
             for (int t = 0; t < 4; t++) {
-                float h = 0.0f;
+                float hv = 0.0f;
                 if (HF) {
                     int16_t m = s0[b][t] < s1[b][t] ? s0[b][t] : s1[b][t];
                     m = m < s2[b][t] ? m : s2[b][t];
-                    h = (float)m * P.hf_vertical_scale;
+                    hv = (float)m * P.hf_vertical_scale;
                 }
-                hh[t] = h;
-                const int i = 4 * c + t;
-                if (i < np) { if (live) mh[i] = h; hsum += root[2] - h; }
+                h[b][t] = hv;
+                const int i = 4 * (sub + b * NV) + t;
+                if (i < np) { if (live) mh[i] = hv; hsum += z - hv; }
             }
-            if (c < nchunk) lds_h[slot + b][threadIdx.x] = make_float4(hh[0], hh[1], hh[2], hh[3]);
+        return hsum;
+    }
+
+    LG_DEV void write_obs(const KArgs &A, int e, int sub, bool live, int64_t step, float root_z) const {
+        const lg_params &P = A.P;
+        float *obs = A.B.obs_buf + (size_t)e * P.num_obs;
+        const int np = P.num_height_points, nchunk = (np + 3) >> 2;
+#pragma unroll
+        for (int b = 0; b < NCH; b++) {
+            const int c = sub + b * NV;
+            if (c < nchunk) {
+                float u[4] = {0, 0, 0, 0};
+                if (P.add_noise) rand4(P.seed, e, step, RNG_NOISE_H, c, u);
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    int i = 4 * c + t;
+                    if (i < np) {
+                        float hh = root_z - 0.5f - h[b][t];
+                        float o = fminf(fmaxf(hh, -1.0f), 1.0f) * P.obs_scale_height;
+                        if (P.add_noise) o += (2.0f * u[t] - 1.0f) * P.noise_height;
+                        o = fminf(fmaxf(o, -P.clip_observations), P.clip_observations);
+                        if (live) obs[48 + i] = o;
+                    }
+                }
+            }
         }
     }
-    return hsum;
-}
+};
 
 // New state of a reset environment (reset_idx :147-191).  Every lane of the env computes the shared part
 // identically; `origin` is in/out (terrain curriculum :446-469), lane-0 writes are done by the caller.
@@ -529,7 +554,7 @@ LG_DEV void reset_values(const KArgs &A, const float *tab, int e, int k, int64_t
 template <class T>
 LG_DEV void write_observations(const KArgs &A, int e, int k, bool live, int64_t step, const float *root, const float (&q)[T::L],
                                const float (&qd)[T::L], const float (&act)[T::L], const float *tab, V3 blv, V3 bav, V3 pg,
-                               const float (&cmd)[4], const float4 (*lds_h)[LG_BLOCK] /* this step's heights, or null: read the buffer */) {
+                               const float (&cmd)[4], bool heights_from_buffer /* k_obs: also the height block, from measured_heights */) {
     constexpr int K = T::K, L = T::L;
     const lg_params &P = A.P;
     float head[12] = {blv.x * P.obs_scale_lin_vel, blv.y * P.obs_scale_lin_vel, blv.z * P.obs_scale_lin_vel,
@@ -568,17 +593,13 @@ LG_DEV void write_observations(const KArgs &A, int e, int k, bool live, int64_t 
             if (live) obs[g * 12 + k * L + j] = o;
         }
     }
-    if (P.measure_heights) {
+    if (P.measure_heights && heights_from_buffer) {
         const float *mh = A.B.measured_heights + (size_t)e * P.num_height_points;
         const int nchunk = (P.num_height_points + 3) >> 2;
-        int slot = 0;
-        for (int c = k; c < nchunk; c += K, slot++) {  // chunk c = points 4c..4c+3, one Philox block each
+        for (int c = k; c < nchunk; c += K) {          // chunk c = points 4c..4c+3, one Philox block each
             float u[4] = {0, 0, 0, 0}, hv[4];
-            if (lds_h) { float4 t4 = lds_h[slot][threadIdx.x]; hv[0] = t4.x; hv[1] = t4.y; hv[2] = t4.z; hv[3] = t4.w; }
-            else {
 #pragma unroll
-                for (int t = 0; t < 4; t++) hv[t] = mh[min(4 * c + t, P.num_height_points - 1)];
-            }
+            for (int t = 0; t < 4; t++) hv[t] = mh[min(4 * c + t, P.num_height_points - 1)];
             if (P.add_noise) rand4(P.seed, e, step, RNG_NOISE_H, c, u);
 #pragma unroll
             for (int t = 0; t < 4; t++) {
@@ -631,41 +652,63 @@ LG_DEV void finish_extras(const KArgs &A, int t, int64_t step_used, bool publish
 // is WAVE-SPECIALISED across the CU's four SIMDs: wave 0 runs the rigid-body step, waves 1..L own the LSTM of joint 0..L-1
 // of every lane (state resident in their registers for the whole step) and compute each sub-step's torques while wave 0
 // does the torque-independent kinematics half.  Hand-over through LDS (lds_x -> lds_tau), two barriers per sub-step.
-template <class T> struct ActuatorWave {
-    // joint j of (env, limb) lane `lane`; must be executed by all 64 lanes of the wave
-    static LG_DEV void run(const KArgs &A, int j, int lane, int d0, bool live, float2 (*lds_x)[LG_BLOCK], float (*lds_tau)[LG_BLOCK], const int *lds_rst) {
+// Post-physics, every variant: the helper waves join the height sampling / height observations (HeightCrew), 4 x the lanes.
+struct StepShared {                                              // LDS hand-over between the rigid-body wave and the helpers
+    float pose[LG_BLOCK][5];                                     // x, y, z, q.z, q.w of the lane's env after the last sub-step
+    float hsum[LG_STEP_WAVES][LG_BLOCK];                         // partial sums of (root z - height) per wave
+    float root_z[LG_BLOCK];                                      // root z after the reset decision (observation input, Q7)
+    int   rst[LG_BLOCK];                                         // reset flag of the lane's env
+};
+template <class T, bool NET, bool HF> struct HelperWave {
+    // wave = 1 .. LG_STEP_WAVES-1; with the actuator net also the LSTM of joint (wave - 1); all 64 lanes active
+    static LG_DEV void run(const KArgs &A, int wave, int lane, int e, int k, int d0, bool live, int64_t step,
+                           float2 (*lds_x)[LG_BLOCK], float (*lds_tau)[LG_BLOCK], StepShared &sh) {
         const lg_buffers &B = A.B;
-        const size_t plane = (size_t)A.P.num_envs * (T::K * T::L);
-        const LstmLane LW = lstm_load(A.weights, lane);
-        float *row[4] = {B.sea_hidden_state + (size_t)(d0 + j) * 8, B.sea_cell_state + (size_t)(d0 + j) * 8,
-                         B.sea_hidden_state + (plane + d0 + j) * 8, B.sea_cell_state + (plane + d0 + j) * 8};   // h0, c0, h1, c1 (anymal.py:65-69)
+        const lg_params &P = A.P;
+        const int j = wave - 1;
         LstmSplit st;
         float (*part[4])[4] = {st.h0, st.c0, st.h1, st.c1};
+        float *row[4] = {nullptr, nullptr, nullptr, nullptr};
+        if (NET) {
+            const size_t plane = (size_t)P.num_envs * (T::K * T::L);
+            const LstmLane LW = lstm_load(A.weights, lane);
+            row[0] = B.sea_hidden_state + (size_t)(d0 + j) * 8; row[1] = B.sea_cell_state + (size_t)(d0 + j) * 8;     // h0, c0, h1, c1 (anymal.py:65-69)
+            row[2] = B.sea_hidden_state + (plane + d0 + j) * 8; row[3] = B.sea_cell_state + (plane + d0 + j) * 8;
 #pragma unroll
-        for (int a = 0; a < 4; a++) {
-            float4 lo = reinterpret_cast<const float4 *>(row[a])[0], hi = reinterpret_cast<const float4 *>(row[a])[1];
-            float u[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-            lstm_split(u, part[a][0], part[a][1]);
-        }
-        for (int it = 0; it < A.P.decimation; it++) {
-            __syncthreads();                                   // this sub-step's (pos_err, vel) are in lds_x
-            const float2 x = lds_x[j][lane];
-            lds_tau[j][lane] = actuator_step_mfma(LW, x.x, x.y, st);
-            __syncthreads();                                   // torques published
-        }
-        __syncthreads();                                       // reset flags published
-        const bool reset = lds_rst[lane] != 0;
-#pragma unroll
-        for (int a = 0; a < 4; a++) {                          // unit-split -> per-row 8-vectors, zeroed for reset envs (anymal.py:59-60)
-            float u[8];
-            lstm_unsplit(part[a][0], part[a][1], u);
-            if (reset) {
-#pragma unroll
-                for (int i = 0; i < 8; i++) u[i] = 0.0f;
+            for (int a = 0; a < 4; a++) {
+                float4 lo = reinterpret_cast<const float4 *>(row[a])[0], hi = reinterpret_cast<const float4 *>(row[a])[1];
+                float u[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                lstm_split(u, part[a][0], part[a][1]);
             }
-            if (live) {
-                reinterpret_cast<float4 *>(row[a])[0] = make_float4(u[0], u[1], u[2], u[3]);
-                reinterpret_cast<float4 *>(row[a])[1] = make_float4(u[4], u[5], u[6], u[7]);
+            for (int it = 0; it < P.decimation; it++) {
+                __syncthreads();                                   // this sub-step's (pos_err, vel) are in lds_x
+                const float2 x = lds_x[j][lane];
+                lds_tau[j][lane] = actuator_step_mfma(LW, x.x, x.y, st);
+                __syncthreads();                                   // torques published
+            }
+        }
+        __syncthreads();                                           // P1: final poses published
+        HeightCrew<T> hc;
+        float hs = 0.0f;
+        if (P.measure_heights) hs = hc.template sample<HF>(A, e, k + T::K * wave, live, sh.pose[lane][0], sh.pose[lane][1], sh.pose[lane][2], sh.pose[lane][3], sh.pose[lane][4]);
+        sh.hsum[wave][lane] = hs;
+        __syncthreads();                                           // P2: partial height sums published
+        __syncthreads();                                           // P3: reset flags / post-reset root z published
+        if (P.measure_heights) hc.write_obs(A, e, k + T::K * wave, live, step, sh.root_z[lane]);
+        if (NET) {
+            const bool reset = sh.rst[lane] != 0;
+#pragma unroll
+            for (int a = 0; a < 4; a++) {                          // unit-split -> per-row 8-vectors, zeroed for reset envs (anymal.py:59-60)
+                float u[8];
+                lstm_unsplit(part[a][0], part[a][1], u);
+                if (reset) {
+#pragma unroll
+                    for (int i = 0; i < 8; i++) u[i] = 0.0f;
+                }
+                if (live) {
+                    reinterpret_cast<float4 *>(row[a])[0] = make_float4(u[0], u[1], u[2], u[3]);
+                    reinterpret_cast<float4 *>(row[a])[1] = make_float4(u[4], u[5], u[6], u[7]);
+                }
             }
         }
     }
@@ -674,16 +717,16 @@ template <class T> struct ActuatorWave {
 // POL: the flat actor (48-128-64-32) runs first on the same four waves (lg_policy.h) and hands the sampled actions over
 // in LDS -- one launch per rollout step instead of policy kernel + step kernel.
 template <class T, bool NET, bool HF, bool POL = false>
-__global__ void __launch_bounds__(NET ? (1 + T::L) * LG_BLOCK : LG_BLOCK) k_step(const KArgs A) {
-    static_assert(!POL || (NET && (1 + T::L) == LG_POLICY_WAVES && T::K * T::L <= 16), "fused policy needs the four-wave actuator-net kernel");
+__global__ void __launch_bounds__(LG_STEP_WAVES * LG_BLOCK) k_step(const KArgs A) {
+    static_assert(!NET || 1 + T::L == LG_STEP_WAVES, "one actuator wave per joint of the limb");
+    static_assert(!POL || (NET && LG_STEP_WAVES == LG_POLICY_WAVES && T::K * T::L <= 16), "fused policy needs the four-wave actuator-net kernel");
     constexpr int K = T::K, L = T::L, ND = K * L, NREP = T::NREP;
     const lg_params &P = A.P;
     const lg_buffers &B = A.B;
     __shared__ float lds_tab[T::K * Tab<T>::STRIDE];
-    __shared__ float4 lds_h[LG_HSLOTS(K)][LG_BLOCK];            // this step's measured heights, [chunk slot of the lane][lane]
     __shared__ float2 lds_x[NET ? L : 1][LG_BLOCK];             // actuator inputs (pos_err, vel) of the sub-step, [joint][lane]
     __shared__ float lds_tau[NET ? L : 1][LG_BLOCK];            // actuator torques of the sub-step
-    __shared__ int lds_rst[LG_BLOCK];                           // reset flag of the lane's env, for the actuator waves' write-back
+    __shared__ StepShared sh;
     __shared__ int s_last;
     __shared__ float4 pol_xa[POL ? 4 : 1][64], pol_xb[POL ? 8 : 1][64], pol_xy[1][64];
     __shared__ float lds_act[POL ? 16 : 1][16];                 // sampled actions [action][env in block]
@@ -691,7 +734,7 @@ __global__ void __launch_bounds__(NET ? (1 + T::L) * LG_BLOCK : LG_BLOCK) k_step
     stage_limb_table<T>(A, lds_tab);
 
     const int N = P.num_envs;
-    const int wave = NET ? (int)(threadIdx.x / LG_BLOCK) : 0, lane = threadIdx.x % LG_BLOCK;
+    const int wave = threadIdx.x / LG_BLOCK, lane = threadIdx.x % LG_BLOCK;
     const int tid = blockIdx.x * LG_BLOCK + lane;
     int e = tid / K;
     const int k = tid % K;
@@ -705,8 +748,8 @@ __global__ void __launch_bounds__(NET ? (1 + T::L) * LG_BLOCK : LG_BLOCK) k_step
         policy_forward<3, 8, 4, 2>(A.pol, pol_xa, pol_xb, pol_xy, blockIdx.x, wave, lane, step, lds_act);
         __syncthreads();
     }
-    if (NET && wave > 0) {
-        ActuatorWave<T>::run(A, wave - 1, lane, d0, live, lds_x, lds_tau, lds_rst);
+    if (wave > 0) {
+        HelperWave<T, NET, HF>::run(A, wave, lane, e, k, d0, live, step, lds_x, lds_tau, sh);
     } else {
     // ---- load persistent state (read once per env-step)
     float root[13], q[L], qd[L], act[L], tau[L];
@@ -773,12 +816,15 @@ __global__ void __launch_bounds__(NET ? (1 + T::L) * LG_BLOCK : LG_BLOCK) k_step
         float heading = atan2f(fwd.y, fwd.x);
         cmd[2] = fminf(fmaxf(0.5f * wrap_to_pi(cmd[3] - heading), -1.0f), 1.0f);
     }
-    float hsum = 0.0f;                                                              // _get_heights :831-869
-    if (P.measure_heights) {
-        // lane k samples (and later consumes, in the observation) the points of chunks c = k, k+K, ...:
-        // no other lane ever reads what this lane writes, so no barrier is needed.
-        hsum = sample_heights<T, HF>(A, e, k, live, root, lds_h);
-    }
+    // _get_heights :831-869, by all four waves (HeightCrew); this wave is virtual lane k of its env
+    sh.pose[lane][0] = root[0]; sh.pose[lane][1] = root[1]; sh.pose[lane][2] = root[2]; sh.pose[lane][3] = root[5]; sh.pose[lane][4] = root[6];
+    __syncthreads();                                               // P1
+    HeightCrew<T> hc;
+    float hsum = 0.0f;
+    if (P.measure_heights) hsum = hc.template sample<HF>(A, e, k, live, root[0], root[1], root[2], root[5], root[6]);
+    sh.hsum[0][lane] = hsum;
+    __syncthreads();                                               // P2
+    hsum = (sh.hsum[0][lane] + sh.hsum[1][lane]) + (sh.hsum[2][lane] + sh.hsum[3][lane]);
     if (P.push_interval > 0 && step % P.push_interval == 0) {                     // _push_robots :438-444
         float u[4];
         rand4(P.seed, e, step, RNG_PUSH, 0, u);
@@ -816,7 +862,6 @@ __global__ void __launch_bounds__(NET ? (1 + T::L) * LG_BLOCK : LG_BLOCK) k_step
     for (int j = 0; j < L; j++) bad |= !isfinite(q[j]) || !isfinite(qd[j]);
     bad = group_or<K>(bad);
     const bool reset = contact_term || time_out || bad;
-    if (NET) { lds_rst[lane] = reset ? 1 : 0; __syncthreads(); }      // actuator waves write their state back (zeroed on reset)
 
     // compute_reward :193-210 ; terms :872-969, cassie.py:43-46
     float last_act[L];
@@ -922,8 +967,12 @@ __global__ void __launch_bounds__(NET ? (1 + T::L) * LG_BLOCK : LG_BLOCK) k_step
         fat = 0.0f; ep_len = 0;     // the actuator state of reset envs is zeroed at write-back (anymal.py:59-60)
     }
 
+    sh.rst[lane] = reset ? 1 : 0; sh.root_z[lane] = root[2];
+    __syncthreads();                                               // P3: helpers write the height observations / actuator state
+
     // compute_observations :130 (stale base-frame quantities for reset envs, as in the reference)
-    write_observations<T>(A, e, k, live, step, root, q, qd, act, tab, blv, bav, pg, cmd, lds_h);
+    write_observations<T>(A, e, k, live, step, root, q, qd, act, tab, blv, bav, pg, cmd, false);
+    if (P.measure_heights) hc.write_obs(A, e, k, live, step, root[2]);
 
     // ---- write persistent state back (written once per env-step)
     if (live) {
@@ -1140,7 +1189,7 @@ __global__ void __launch_bounds__(LG_BLOCK) k_obs(const KArgs A) {
     V3 blv = v3(B.base_lin_vel[(size_t)e * 3], B.base_lin_vel[(size_t)e * 3 + 1], B.base_lin_vel[(size_t)e * 3 + 2]);
     V3 bav = v3(B.base_ang_vel[(size_t)e * 3], B.base_ang_vel[(size_t)e * 3 + 1], B.base_ang_vel[(size_t)e * 3 + 2]);
     V3 pg = v3(B.projected_gravity[(size_t)e * 3], B.projected_gravity[(size_t)e * 3 + 1], B.projected_gravity[(size_t)e * 3 + 2]);
-    write_observations<T>(A, e, k, live, A.step, root, q, qd, act, tab, blv, bav, pg, cmd, nullptr);
+    write_observations<T>(A, e, k, live, A.step, root, q, qd, act, tab, blv, bav, pg, cmd, true);
 }
 
 // ====================================================================  host side: C-ABI  ====================================================================
@@ -1429,13 +1478,13 @@ int lg_step(lg_sim *s, const float *actions, int64_t common_step_counter, void *
     const bool hf = s->P.terrain_type == LG_TERRAIN_HEIGHTFIELD;
     const bool net = s->P.control_type == LG_CTRL_ACTUATOR_NET;
     if (s->kind == ROBOT_ANYMAL) {
-        dim3 g(grid_for<AnymalTraits>(s->P.num_envs)), b(LG_BLOCK);
-        if (net && !hf) hipLaunchKernelGGL((k_step<AnymalTraits, true, false>), g, dim3((1 + AnymalTraits::L) * LG_BLOCK), 0, st, a);
-        else if (net && hf) hipLaunchKernelGGL((k_step<AnymalTraits, true, true>), g, dim3((1 + AnymalTraits::L) * LG_BLOCK), 0, st, a);
+        dim3 g(grid_for<AnymalTraits>(s->P.num_envs)), b(LG_STEP_WAVES * LG_BLOCK);
+        if (net && !hf) hipLaunchKernelGGL((k_step<AnymalTraits, true, false>), g, b, 0, st, a);
+        else if (net && hf) hipLaunchKernelGGL((k_step<AnymalTraits, true, true>), g, b, 0, st, a);
         else if (!net && !hf) hipLaunchKernelGGL((k_step<AnymalTraits, false, false>), g, b, 0, st, a);
         else hipLaunchKernelGGL((k_step<AnymalTraits, false, true>), g, b, 0, st, a);
     } else {
-        dim3 g(grid_for<CassieTraits>(s->P.num_envs)), b(LG_BLOCK);
+        dim3 g(grid_for<CassieTraits>(s->P.num_envs)), b(LG_STEP_WAVES * LG_BLOCK);
         if (!hf) hipLaunchKernelGGL((k_step<CassieTraits, false, false>), g, b, 0, st, a);
         else hipLaunchKernelGGL((k_step<CassieTraits, false, true>), g, b, 0, st, a);
     }
@@ -1454,7 +1503,7 @@ int lg_step_policy(lg_sim *s, lg_policy *p, const float *obs, float *actions, fl
         return fail(-4, "the fused policy step is compiled for the 48-128-64-32 actor on the quadruped actuator-net plane kernel; use lg_policy_act + lg_step");
     KArgs a; fill_args(s, a, common_step_counter); a.actions_in = nullptr;
     fill_policy_args(p, a.pol, obs, actions, mean, s->P.num_envs, seed, common_step_counter, s->B.step_counter, deterministic);
-    hipLaunchKernelGGL((k_step<AnymalTraits, true, false, true>), dim3(grid_for<AnymalTraits>(s->P.num_envs)), dim3((1 + AnymalTraits::L) * LG_BLOCK),
+    hipLaunchKernelGGL((k_step<AnymalTraits, true, false, true>), dim3(grid_for<AnymalTraits>(s->P.num_envs)), dim3(LG_STEP_WAVES * LG_BLOCK),
                        0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return 0;
