@@ -658,7 +658,41 @@ struct StepShared {                                              // LDS hand-ove
     float hsum[LG_STEP_WAVES][LG_BLOCK];                         // partial sums of (root z - height) per wave
     float root_z[LG_BLOCK];                                      // root z after the reset decision (observation input, Q7)
     int   rst[LG_BLOCK];                                         // reset flag of the lane's env
+    float r_t[LG_NUM_REWARD_TERMS][LG_BLOCK];                    // this step's scaled reward terms, for the episode-sum bookkeeping
 };
+// episode_sums[name] += term (:203); read + zeroed for reset envs, whose sums feed extras["episode"] (reset_idx :179-183).
+// Runs on a helper wave (one lane per env): off the rigid-body wave's critical path.
+struct EpisodeSums {
+    float sum[LG_NUM_REWARD_TERMS];
+    LG_DEV void load(const KArgs &A, int e) {                     // issued early: the running sums do not depend on this step
+#pragma unroll
+        for (int t = 0; t < LG_NUM_REWARD_TERMS; t++) {
+            const int slot = A.P.reward_slot[t];
+            sum[t] = slot >= 0 ? A.B.episode_sums[(size_t)slot * A.P.num_envs + e] : 0.0f;
+        }
+    }
+    LG_DEV void update(const KArgs &A, int e, int lane, const StepShared &sh) {
+        const lg_params &P = A.P;
+        const bool reset = sh.rst[lane] != 0;
+#pragma unroll
+        for (int t = 0; t < LG_NUM_REWARD_TERMS; t++) {
+            const int slot = P.reward_slot[t];
+            if (slot >= 0) {
+                sum[t] += sh.r_t[t][lane];
+                A.B.episode_sums[(size_t)slot * P.num_envs + e] = reset ? 0.0f : sum[t];
+            }
+        }
+        if (reset) {
+#pragma unroll
+            for (int t = 0; t < LG_NUM_REWARD_TERMS; t++) {
+                const int slot = P.reward_slot[t];
+                if (slot >= 0) atomicAdd(A.B.extras_accum + slot, sum[t]);
+            }
+            atomicAdd(A.B.extras_accum + P.num_reward_slots, 1.0f);
+        }
+    }
+};
+
 template <class T, bool NET, bool HF> struct HelperWave {
     // wave = 1 .. LG_STEP_WAVES-1; with the actuator net also the LSTM of joint (wave - 1); all 64 lanes active
     static LG_DEV void run(const KArgs &A, int wave, int lane, int e, int k, int d0, bool live, int64_t step,
@@ -693,7 +727,11 @@ template <class T, bool NET, bool HF> struct HelperWave {
         if (P.measure_heights) hs = hc.template sample<HF>(A, e, k + T::K * wave, live, sh.pose[lane][0], sh.pose[lane][1], sh.pose[lane][2], sh.pose[lane][3], sh.pose[lane][4]);
         sh.hsum[wave][lane] = hs;
         __syncthreads();                                           // P2: partial height sums published
-        __syncthreads();                                           // P3: reset flags / post-reset root z published
+        const bool keeper = wave == 1 && live && k == 0;           // one lane per env keeps the episode sums
+        EpisodeSums es;
+        if (keeper) es.load(A, e);
+        __syncthreads();                                           // P3: reset flags / post-reset root z / reward terms published
+        if (keeper) es.update(A, e, lane, sh);
         if (P.measure_heights) hc.write_obs(A, e, k + T::K * wave, live, step, sh.root_z[lane]);
         if (NET) {
             const bool reset = sh.rst[lane] != 0;
@@ -840,6 +878,7 @@ __global__ void __launch_bounds__(LG_STEP_WAVES * LG_BLOCK) k_step(const KArgs A
         for (int r = 0; r < NREP; r++) { cf[3 * r] = Frep[r][0]; cf[3 * r + 1] = Frep[r][1]; cf[3 * r + 2] = Frep[r][2]; }
         if (k == 0) { float *c0 = B.contact_forces + (size_t)e * (1 + K * NREP) * 3; c0[0] = Fbase[0]; c0[1] = Fbase[1]; c0[2] = Fbase[2]; }
     }
+    LG_PROF(9);
     // check_termination :139-145
     int term_local = 0;
     float coll_local = 0.0f;
@@ -925,36 +964,20 @@ __global__ void __launch_bounds__(LG_STEP_WAVES * LG_BLOCK) k_step(const KArgs A
         term[LG_REW_TRACKING_LIN_VEL] = __expf(-(ex * ex + ey * ey) / P.tracking_sigma);
         term[LG_REW_TRACKING_ANG_VEL] = __expf(-(ew * ew) / P.tracking_sigma);
     }
+    LG_PROF(10);
     float rew = 0.0f;
     const bool writer = live && k == 0;
+    float r_t[LG_NUM_REWARD_TERMS];                     // scaled terms; exactly 0 for disabled ones (x + 0 == x: the sum order is the oracle's)
 #pragma unroll
-    for (int t = 0; t < LG_NUM_REWARD_TERMS; t++) {
-        if (t == LG_REW_TERMINATION) continue;
-        const int slot = P.reward_slot[t];
-        if (slot < 0) continue;
-        float r = term[t] * P.reward_scale[t];
-        rew += r;
-        if (writer) {
-            float *es = B.episode_sums + (size_t)slot * N + e;
-            float sum = *es + r;
-            *es = reset ? 0.0f : sum;
-            if (reset) atomicAdd(B.extras_accum + slot, sum);          // extras["episode"] numerator (:179-183)
-        }
-    }
-    if (writer && reset) atomicAdd(B.extras_accum + P.num_reward_slots, 1.0f);
+    for (int t = 0; t < LG_NUM_REWARD_TERMS; t++) r_t[t] = (P.reward_slot[t] >= 0) ? term[t] * P.reward_scale[t] : 0.0f;
+#pragma unroll
+    for (int t = 0; t < LG_NUM_REWARD_TERMS; t++) if (t != LG_REW_TERMINATION) rew += r_t[t];
     if (P.only_positive_rewards) rew = fmaxf(rew, 0.0f);
-    if (P.reward_slot[LG_REW_TERMINATION] >= 0) {
-        const int slot = P.reward_slot[LG_REW_TERMINATION];
-        float r = term[LG_REW_TERMINATION] * P.reward_scale[LG_REW_TERMINATION];
-        rew += r;
-        if (writer) {
-            float *es = B.episode_sums + (size_t)slot * N + e;
-            float sum = *es + r;
-            *es = reset ? 0.0f : sum;
-            if (reset) atomicAdd(B.extras_accum + slot, sum);          // extras["episode"] numerator (:179-183)
-        }
-    }
+    rew += r_t[LG_REW_TERMINATION];                     // added after the clip (:208-210)
+#pragma unroll
+    for (int t = 0; t < LG_NUM_REWARD_TERMS; t++) sh.r_t[t][lane] = r_t[t];       // episode sums: helper wave, after P3
 
+    LG_PROF(11);
     // reset_idx for terminated envs (predicated epilogue) :128-129, anymal.py:56-60
     float origin[3] = {B.env_origins[(size_t)e * 3], B.env_origins[(size_t)e * 3 + 1], B.env_origins[(size_t)e * 3 + 2]};
     if (reset) {
@@ -970,10 +993,12 @@ __global__ void __launch_bounds__(LG_STEP_WAVES * LG_BLOCK) k_step(const KArgs A
     sh.rst[lane] = reset ? 1 : 0; sh.root_z[lane] = root[2];
     __syncthreads();                                               // P3: helpers write the height observations / actuator state
 
+    LG_PROF(12);
     // compute_observations :130 (stale base-frame quantities for reset envs, as in the reference)
     write_observations<T>(A, e, k, live, step, root, q, qd, act, tab, blv, bav, pg, cmd, false);
     if (P.measure_heights) hc.write_obs(A, e, k, live, step, root[2]);
 
+    LG_PROF(13);
     // ---- write persistent state back (written once per env-step)
     if (live) {
 #pragma unroll
