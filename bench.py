@@ -178,7 +178,7 @@ def main():
                          "traffic": traffic, "traffic_source": "profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, 2*FETCH+WRITE KiB)" if traffic else None, "kernel": ("k_step<AnymalTraits,NET,plane,POL> (actor + step)" if fused_step else "k_step<AnymalTraits,NET,plane>") if a.task != "cassie" else "k_step<CassieTraits>",
                          "kernel_ms": kern_ms, "kernel_ms_method": f"HIP events around {n_rep} replays of a HIP graph of {KG} back-to-back launches of the step kernel alone, right after the timed region (per-launch average, includes ~1 us launch gap)",
                          "algorithmic_bytes_per_env_step": bpe,
-                         "note": "fused step is VALU/latency-bound at 4096 envs (256 waves on 1024 SIMDs); see DESIGN.md"},
+                         "note": "issue/latency-bound, not HBM-bound: 4096 envs = 256 workgroups x (1 rigid-body + 3 helper waves), one wave per SIMD, ~20k serial instructions on the rigid-body wave at one per ~6.5 cycles; see DESIGN.md section 5"},
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a)
