@@ -58,7 +58,7 @@ class RolloutStorage:
             delta = self.rewards[step] + not_done * gamma * nxt - self.values[step]
             adv = delta + not_done * gamma * lam * adv
             self.returns[step] = adv + self.values[step]
-        self.advantages = self.returns - self.values
+        torch.sub(self.returns, self.values, out=self.advantages)        # in place: a captured update graph reads this buffer
         if _world() > 1:
             fused = torch.cat((self.returns.flatten(), self.advantages.flatten()))
             gathered = torch.empty(_world() * fused.numel(), device=fused.device, dtype=fused.dtype)
@@ -67,7 +67,7 @@ class RolloutStorage:
             mean, std = all_adv.mean(), all_adv.std()
         else:
             mean, std = self.advantages.mean(), self.advantages.std()
-        self.advantages = (self.advantages - mean) / (std + 1e-8)
+        self.advantages.sub_(mean).div_(std + 1e-8)
 
     def get_statistics(self):
         done = self.dones.clone()
@@ -95,12 +95,28 @@ class RolloutStorage:
 class PPO:
     def __init__(self, actor_critic, num_learning_epochs=1, num_mini_batches=1, clip_param=0.2, gamma=0.998, lam=0.95,
                  value_loss_coef=1.0, entropy_coef=0.0, learning_rate=1e-3, max_grad_norm=1.0,
-                 use_clipped_value_loss=True, schedule="fixed", desired_kl=0.01, device="cpu"):
+                 use_clipped_value_loss=True, schedule="fixed", desired_kl=0.01, device="cpu", graphed_update=True):
         self.device = device
+        # Single-GPU runs replay one captured HIP graph per mini-batch step (forward, losses, backward, grad clip, Adam and
+        # the adaptive-KL learning rate all on the device): the flat networks' update is launch-bound (~150 tiny kernels).
+        self._graph_ok = bool(graphed_update) and str(device).startswith("cuda")
+        self._graph = None
+        self._updates_done = 0
         self.desired_kl, self.schedule, self.learning_rate = desired_kl, schedule, learning_rate
         self.actor_critic = actor_critic.to(device)
         self.storage = None
-        self.optimizer = optim.Adam(self.actor_critic.parameters(), lr=learning_rate)
+        if self._graph_ok:
+            # The CUDA generator allocates its graph-safe state tensors at the first capture in the process; if that happens
+            # under torch.inference_mode (the rollout graph, rl/runner.py) they become inference tensors and a later capture
+            # with autograd enabled cannot touch them.  Prime them here, in normal mode.
+            # (kept alive: the generator drops the tensors again when its last graph goes away)
+            self._prime = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._prime):
+                torch.zeros(1, device=device).add_(1.0)
+            self._lr = torch.tensor(float(learning_rate), device=device)
+            self.optimizer = optim.Adam(self.actor_critic.parameters(), lr=self._lr, capturable=True)
+        else:
+            self.optimizer = optim.Adam(self.actor_critic.parameters(), lr=learning_rate)
         self.transition = RolloutStorage.Transition()
         self.clip_param, self.num_learning_epochs, self.num_mini_batches = clip_param, num_learning_epochs, num_mini_batches
         self.value_loss_coef, self.entropy_coef = value_loss_coef, entropy_coef
@@ -152,7 +168,98 @@ class PPO:
             g.copy_(flat[o:o + g.numel()].view_as(g))
             o += g.numel()
 
+    def after_optimizer_load(self):
+        """The optimiser's tensors were replaced (checkpoint resume): re-link the device learning rate, drop the captured graph."""
+        if self._graph_ok:
+            for g in self.optimizer.param_groups:
+                self._lr.copy_(torch.as_tensor(g["lr"], device=self.device).float().reshape(()))
+                g["lr"] = self._lr
+            self._graph, self._updates_done = None, 0
+
+    # ------------------------------------------------------------------ captured mini-batch step
+    def _flat(self):
+        st = self.storage
+        obs = st.observations.flatten(0, 1)
+        cobs = st.privileged_observations.flatten(0, 1) if st.privileged_observations is not None else obs
+        return (obs, cobs, st.actions.flatten(0, 1), st.values.flatten(0, 1), st.advantages.flatten(0, 1), st.returns.flatten(0, 1),
+                st.actions_log_prob.flatten(0, 1), st.mu.flatten(0, 1), st.sigma.flatten(0, 1))
+
+    def _mb_step(self):
+        """One mini-batch step on the rows listed in ``self._ix``; everything stays on the device (no host decisions)."""
+        ix = self._ix
+        obs, cobs, act, tval, adv, ret, old_lp, old_mu, old_sig = (t[ix] for t in self._flat())
+        ac = self.actor_critic
+        ac.update_distribution(obs)
+        lp = ac.get_actions_log_prob(act)
+        val = ac.evaluate(cobs)
+        mu, sig, ent = ac.action_mean, ac.action_std, ac.entropy
+        if self.desired_kl is not None and self.schedule == "adaptive":
+            with torch.no_grad():
+                kl = torch.sum(torch.log(sig / old_sig + 1.0e-5) + (old_sig.square() + (old_mu - mu).square()) / (2.0 * sig.square()) - 0.5, dim=-1).mean()
+                lr = self._lr
+                down, up = torch.clamp(lr / 1.5, min=1e-5), torch.clamp(lr * 1.5, max=1e-2)
+                self._lr.copy_(torch.where(kl > self.desired_kl * 2.0, down, torch.where((kl < self.desired_kl / 2.0) & (kl > 0.0), up, lr)))
+        ratio = torch.exp(lp - torch.squeeze(old_lp))
+        a = torch.squeeze(adv)
+        surrogate = torch.max(-a * ratio, -a * torch.clamp(ratio, 1.0 - self.clip_param, 1.0 + self.clip_param)).mean()
+        if self.use_clipped_value_loss:
+            vclip = tval + (val - tval).clamp(-self.clip_param, self.clip_param)
+            vloss = torch.max((val - ret).pow(2), (vclip - ret).pow(2)).mean()
+        else:
+            vloss = (ret - val).pow(2).mean()
+        loss = surrogate + self.value_loss_coef * vloss - self.entropy_coef * ent.mean()
+        loss.backward()
+        nn.utils.clip_grad_norm_(self.actor_critic.parameters(), self.max_grad_norm)
+        self.optimizer.step()
+        with torch.no_grad():
+            self._acc[0] += vloss.detach()
+            self._acc[1] += surrogate.detach()
+
+    def _update_graphed(self):
+        st = self.storage
+        B = st.num_envs * st.num_transitions_per_env
+        mb = B // self.num_mini_batches
+        if self._graph is None:
+            self._ix = torch.zeros(mb, dtype=torch.int64, device=self.device)
+            self._acc = torch.zeros(2, device=self.device)
+        self._acc.zero_()
+        # The first update runs eagerly ON THE CAPTURE STREAM: it is the warm-up torch asks for before capturing autograd +
+        # optimiser work (library handles / workspaces and the optimiser state get created on that stream, outside capture).
+        if self._graph is None and not hasattr(self, "_gstream"):
+            self._gstream = torch.cuda.Stream(device=self.device)
+        capture_now = self._graph is None and self._updates_done >= 1
+        cur = torch.cuda.current_stream(self.device)
+        for _ in range(self.num_learning_epochs):
+            perm = torch.randperm(self.num_mini_batches * mb, device=self.device)
+            for i in range(self.num_mini_batches):
+                self._ix.copy_(perm[i * mb:(i + 1) * mb])
+                if self._graph is not None:
+                    self._graph.replay()
+                    continue
+                self._gstream.wait_stream(cur)
+                if capture_now:
+                    self.optimizer.zero_grad(set_to_none=True)
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=self._gstream):
+                        self._mb_step()
+                    self._graph = g
+                    capture_now = False
+                    g.replay()                               # the capture did not execute: run this mini-batch now
+                else:
+                    with torch.cuda.stream(self._gstream):
+                        self.optimizer.zero_grad(set_to_none=True)
+                        self._mb_step()
+                    cur.wait_stream(self._gstream)
+        n = self.num_learning_epochs * self.num_mini_batches
+        mean_v, mean_s, lr = (float(x) for x in torch.cat((self._acc / n, self._lr.view(1))).cpu())
+        self.learning_rate = lr
+        self._updates_done += 1
+        st.clear()
+        return mean_v, mean_s
+
     def update(self):
+        if self._graph_ok and _world() == 1:
+            return self._update_graphed()
         mean_v, mean_s = 0.0, 0.0
         gen = self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs)
         for obs, cobs, act, tval, adv, ret, old_lp, old_mu, old_sig, _, _ in gen:
