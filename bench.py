@@ -83,7 +83,7 @@ def main():
     policy = ActorCritic(env.num_obs, env.num_obs, env.num_actions, **pol).to(dev)
     with contextlib.redirect_stdout(io.StringIO()):
         obs, _ = env.reset()
-    use_torch = a.torch_policy or a.policy == "torch" or (a.policy == "auto" and max(pol["actor_hidden_dims"]) > 128)
+    use_torch = a.torch_policy or a.policy == "torch"      # "auto" = the MFMA actor (all compiled shapes beat torch/hipBLASLt since the weight prefetch)
     a.torch_policy = use_torch
     if use_torch:
         policy_act = policy.act

@@ -49,6 +49,8 @@ struct KArgs {                 // passed by value: lives in the kernarg segment 
     lg_buffers B;
     BaseTab    base;
     const float *limb_table;   // [K][STRIDE] device
+    const float *hpts;         // [LG_MAX_HEIGHT_POINTS][2] device copy of P.height_points: a lane-dependent index into the
+                               // by-value kernarg struct makes the compiler copy all of KArgs to scratch (3 KB per lane)
     const float *weights;      // [LW_ROWS][64] per-lane MFMA operand table of the actuator net, or null
     const float *actions_in;   // [N, ndof]
     const int32_t *env_ids;    // reset kernel only
@@ -455,7 +457,7 @@ template <class T> struct HeightCrew {
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
                     int i = min(4 * (sub + b * NV) + t, np - 1);                   // clamped: the tail re-reads a valid point
-                    V3 p = quat_apply(qy, v3(P.height_points[i][0], P.height_points[i][1], 0.0f));
+                    V3 p = quat_apply(qy, v3(A.hpts[2 * i], A.hpts[2 * i + 1], 0.0f));
                     float px = p.x + x + P.hf_border, py = p.y + y + P.hf_border;
                     int ix = (int)(px / P.hf_horizontal_scale), iy = (int)(py / P.hf_horizontal_scale);   // .long(): truncation; int32 saturates, then clamps
                     ix = min(max(ix, 0), P.hf_rows - 2); iy = min(max(iy, 0), P.hf_cols - 2);
@@ -1304,6 +1306,7 @@ static int upload_tables(lg_sim *s) {
     if (s->kind == ROBOT_ANYMAL) { fill_limb_table<AnymalTraits>(s->P, s->M, host); n = AnymalTraits::K * Tab<AnymalTraits>::STRIDE; }
     else { fill_limb_table<CassieTraits>(s->P, s->M, host); n = CassieTraits::K * Tab<CassieTraits>::STRIDE; }
     HIP_TRY(hipMemcpy(s->d_limb_table, host, n * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->d_limb_table + LG_MAX_LIMBS * (LG_MAX_CHAIN * LG_JS + 4 * LG_MAX_LIMB_POINTS + 1), s->P.height_points, sizeof(float) * 2 * LG_MAX_HEIGHT_POINTS, hipMemcpyHostToDevice));
     s->base.mass = s->M.base_mass;
     memcpy(s->base.com, s->M.base_com, 12); memcpy(s->base.inertia, s->M.base_inertia, 24);
     memset(s->base.pts, 0, sizeof s->base.pts);
@@ -1313,7 +1316,7 @@ static int upload_tables(lg_sim *s) {
 }
 
 static void fill_args(const lg_sim *s, KArgs &a, int64_t step) {
-    a.P = s->P; a.B = s->B; a.base = s->base; a.limb_table = s->d_limb_table; a.weights = s->d_weights;
+    a.P = s->P; a.B = s->B; a.base = s->base; a.limb_table = s->d_limb_table; a.hpts = s->d_limb_table + LG_MAX_LIMBS * (LG_MAX_CHAIN * LG_JS + 4 * LG_MAX_LIMB_POINTS + 1); a.weights = s->d_weights;
     a.actions_in = nullptr; a.env_ids = nullptr; a.count = 0; a.step = step; memset(&a.pol, 0, sizeof a.pol);
     a.penalised_mask = s->M.penalised_mask; a.termination_mask = s->M.termination_mask; a.done_counter = s->d_done; a.prof = s->d_prof;
 }
@@ -1442,7 +1445,7 @@ int lg_create(const lg_params *params, const lg_robot_model *model, const float 
 #ifdef LG_PROFILE
     if (hipMalloc(&s->d_prof, sizeof(unsigned long long) * LG_NPROF) != hipSuccess || hipMemset(s->d_prof, 0, sizeof(unsigned long long) * LG_NPROF) != hipSuccess) { delete s; return fail(-10, "hipMalloc failed"); }
 #endif
-    if (hipMalloc(&s->d_limb_table, sizeof(float) * LG_MAX_LIMBS * (LG_MAX_CHAIN * LG_JS + 4 * LG_MAX_LIMB_POINTS + 1)) != hipSuccess) { delete s; return fail(-10, "hipMalloc failed"); }
+    if (hipMalloc(&s->d_limb_table, sizeof(float) * (LG_MAX_LIMBS * (LG_MAX_CHAIN * LG_JS + 4 * LG_MAX_LIMB_POINTS + 1) + 2 * LG_MAX_HEIGHT_POINTS)) != hipSuccess) { delete s; return fail(-10, "hipMalloc failed"); }
     if (s->has_net) {
         float table[LW_ROWS * 64];
         build_lstm_table(actuator_weights, table);

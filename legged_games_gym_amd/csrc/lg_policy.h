@@ -26,6 +26,9 @@ LG_DEV float elu1(float x) { return x > 0.0f ? x : (__builtin_amdgcn_exp2f(1.442
 template <int IN_T, int OUT_T, bool ACT>
 LG_DEV void mlp_layer(const float *__restrict__ w /* [OUT_T][IN_T*4][64] */, const float *__restrict__ b /* [OUT_T][4][64] */,
                       const float4 (*xin)[64], float4 (*xout)[64], int wave, int lane) {
+    // All IN_T*4 weight words of an output tile are requested before the first MFMA consumes one: a lone wave otherwise
+    // keeps only ~16 of these L2 loads in flight and the 512-wide actors become load-latency bound (95 us per call).
+    constexpr int CH = IN_T > 16 ? 16 : IN_T;                      // K tiles per register batch (64 VGPRs)
 #pragma unroll 1
     for (int o = wave; o < OUT_T; o += LG_POLICY_WAVES) {
         f32x4 acc;
@@ -33,12 +36,21 @@ LG_DEV void mlp_layer(const float *__restrict__ w /* [OUT_T][IN_T*4][64] */, con
         for (int r = 0; r < 4; r++) acc[r] = b[(o * 4 + r) * 64 + lane];
         const float *wo = w + (size_t)o * IN_T * 4 * 64 + lane;
 #pragma unroll
-        for (int t = 0; t < IN_T; t++) {
-            const float4 xv = xin[t][lane];
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wo[(t * 4 + 0) * 64], xv.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wo[(t * 4 + 1) * 64], xv.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wo[(t * 4 + 2) * 64], xv.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wo[(t * 4 + 3) * 64], xv.w, acc, 0, 0, 0);
+        for (int t0 = 0; t0 < IN_T; t0 += CH) {
+            float wr[CH * 4];
+#pragma unroll
+            for (int i = 0; i < CH * 4; i++) wr[i] = (t0 * 4 + i < IN_T * 4) ? wo[(t0 * 4 + i) * 64] : 0.0f;
+            __builtin_amdgcn_sched_barrier(0);                     // keep the scheduler from re-interleaving loads and MFMAs
+#pragma unroll
+            for (int t = 0; t < CH; t++) {
+                if (t0 + t < IN_T) {
+                    const float4 xv = xin[t0 + t][lane];
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[t * 4 + 0], xv.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[t * 4 + 1], xv.y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[t * 4 + 2], xv.z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[t * 4 + 3], xv.w, acc, 0, 0, 0);
+                }
+            }
         }
         xout[o][lane] = ACT ? make_float4(elu1(acc[0]), elu1(acc[1]), elu1(acc[2]), elu1(acc[3])) : make_float4(acc[0], acc[1], acc[2], acc[3]);
     }
