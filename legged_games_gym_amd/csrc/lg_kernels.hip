@@ -93,25 +93,40 @@ __device__ __forceinline__ void lg_prof(int idx, unsigned long long *out) {
 enum { PF_PROLOGUE = 0, PF_TORQUE, PF_KINEMATICS, PF_INWARD, PF_BASE, PF_OUTWARD, PF_INTEGRATE, PF_POST, PF_EXTRAS };
 
 // ------------------------------------------------------------------ terrain
-template <bool HF> LG_DEV void ground_query(const KArgs &A, float x, float y, float &h, V3 &n) {
-    if (!HF) { h = 0.0f; n = v3(0, 0, 1); return; }
+// Split in two so the four samples of EVERY collision point of a sub-step are in flight before the first is consumed
+// (the table is L2-resident but ~1 us away for a lone wave): hf_fetch issues the loads, hf_eval does the bilinear patch.
+struct HfFetch { int16_t s00, s10, s01, s11; float tx, ty; };
+template <bool HF> LG_DEV HfFetch hf_fetch(const KArgs &A, float x, float y) {
+    HfFetch f; f.s00 = f.s10 = f.s01 = f.s11 = 0; f.tx = f.ty = 0.0f;
+    if (!HF) return f;
     const lg_params &P = A.P;
     float inv = 1.0f / P.hf_horizontal_scale;
     float gx = (x + P.hf_border) * inv, gy = (y + P.hf_border) * inv;
     float fx = floorf(gx), fy = floorf(gy);
     int ix = (int)fx, iy = (int)fy;
-    float tx = gx - fx, ty = gy - fy;
+    f.tx = gx - fx; f.ty = gy - fy;
     auto at = [&](int i, int j) {
         i = min(max(i, 0), P.hf_rows - 1); j = min(max(j, 0), P.hf_cols - 1);
-        return (float)A.B.height_samples[(size_t)i * P.hf_cols + j] * P.hf_vertical_scale;
+        return A.B.height_samples[(size_t)i * P.hf_cols + j];
     };
-    float h00 = at(ix, iy), h10 = at(ix + 1, iy), h01 = at(ix, iy + 1), h11 = at(ix + 1, iy + 1);
-    float hx0 = h00 + (h10 - h00) * tx, hx1 = h01 + (h11 - h01) * tx;
-    h = hx0 + (hx1 - hx0) * ty;
-    float dhdx = ((h10 - h00) + ((h11 - h01) - (h10 - h00)) * ty) * inv;
+    f.s00 = at(ix, iy); f.s10 = at(ix + 1, iy); f.s01 = at(ix, iy + 1); f.s11 = at(ix + 1, iy + 1);
+    return f;
+}
+template <bool HF> LG_DEV void hf_eval(const KArgs &A, const HfFetch &f, float &h, V3 &n) {
+    if (!HF) { h = 0.0f; n = v3(0, 0, 1); return; }
+    const lg_params &P = A.P;
+    float inv = 1.0f / P.hf_horizontal_scale;
+    float h00 = (float)f.s00 * P.hf_vertical_scale, h10 = (float)f.s10 * P.hf_vertical_scale;
+    float h01 = (float)f.s01 * P.hf_vertical_scale, h11 = (float)f.s11 * P.hf_vertical_scale;
+    float hx0 = h00 + (h10 - h00) * f.tx, hx1 = h01 + (h11 - h01) * f.tx;
+    h = hx0 + (hx1 - hx0) * f.ty;
+    float dhdx = ((h10 - h00) + ((h11 - h01) - (h10 - h00)) * f.ty) * inv;
     float dhdy = (hx1 - hx0) * inv;
     float l = 1.0f / sqrtf(dhdx * dhdx + dhdy * dhdy + 1.0f);
     n = v3(-dhdx * l, -dhdy * l, l);
+}
+template <bool HF> LG_DEV void ground_query(const KArgs &A, float x, float y, float &h, V3 &n) {
+    hf_eval<HF>(A, hf_fetch<HF>(A, x, y), h, n);
 }
 
 // ------------------------------------------------------------------ one 5 ms rigid-body step for (env, limb)
@@ -216,6 +231,7 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, int lane_k, float 
     AI I0[L], I0b;
     S6 p0[L], p0b;
     Contact cb, cl[NPT];
+    HfFetch fb, fl[NPT];               // ground samples of all collision points: fetched here, evaluated after the loop
     {
         float sc = base_mass / A.base.mass, Il[6];
 #pragma unroll
@@ -228,11 +244,10 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, int lane_k, float 
             float bp[4] = {A.base.pts[0][0], A.base.pts[0][1], A.base.pts[0][2], A.base.pts[0][3]};
 #pragma unroll
             for (int i = 1; i < K; i++) if (lane_k == i) { bp[0] = A.base.pts[i][0]; bp[1] = A.base.pts[i][1]; bp[2] = A.base.pts[i][2]; bp[3] = A.base.pts[i][3]; }
-            V3 r = mul(R0, v3(bp[0], bp[1], bp[2]));
-            float h; V3 n;
-            ground_query<HF>(A, root[0] + r.x, root[1] + r.y, h, n);
-            contact_setup(cb, P, mu, r, n, bp[3] - (root[2] + r.z - h) * n.z, v0 + cross(w0, r), v3(Fbase[0], Fbase[1], Fbase[2]));
-            cb.on = cb.on && (lane_k < A.base.num_pts);
+            cb.r = mul(R0, v3(bp[0], bp[1], bp[2]));
+            cb.vc = v0 + cross(w0, cb.r);
+            cb.depth = bp[3];                                            // radius until the ground height arrives
+            fb = hf_fetch<HF>(A, root[0] + cb.r.x, root[1] + cb.r.y);
         }
     }
     {
@@ -268,14 +283,26 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, int lane_k, float 
 #pragma unroll
             for (int i = 0; i < NPT; i++) if (T::pt_joint(i) == j) {
                 const float *tp = tab + L * LG_JS + 4 * i;
-                V3 r = mul(Rj, v3(tp[0], tp[1], tp[2]));
-                V3 pw = rj + r;
-                float h; V3 n;
-                ground_query<HF>(A, root[0] + pw.x, root[1] + pw.y, h, n);
-                contact_setup(cl[i], P, mu, r, n, tp[3] - (root[2] + pw.z - h) * n.z, vj + cross(wj, r),
-                              v3(Frep[T::pt_rep(i)][0], Frep[T::pt_rep(i)][1], Frep[T::pt_rep(i)][2]));
+                cl[i].r = mul(Rj, v3(tp[0], tp[1], tp[2]));
+                V3 pw = rj + cl[i].r;
+                cl[i].vc = vj + cross(wj, cl[i].r);
+                cl[i].depth = tp[3];                                     // radius, for now
+                cl[i].vtn = root[2] + pw.z;                              // point height, for now
+                fl[i] = hf_fetch<HF>(A, root[0] + pw.x, root[1] + pw.y);
             }
             Rpar = Rj; rpar = rj; wpar = wj; vpar = vj;
+        }
+    }
+    {   // the samples have had the whole kinematics pass to arrive
+        float h; V3 n;
+        hf_eval<HF>(A, fb, h, n);
+        contact_setup(cb, P, mu, cb.r, n, cb.depth - (root[2] + cb.r.z - h) * n.z, cb.vc, v3(Fbase[0], Fbase[1], Fbase[2]));
+        cb.on = cb.on && (lane_k < A.base.num_pts);
+#pragma unroll
+        for (int i = 0; i < NPT; i++) {
+            hf_eval<HF>(A, fl[i], h, n);
+            contact_setup(cl[i], P, mu, cl[i].r, n, cl[i].depth - (cl[i].vtn - h) * n.z, cl[i].vc,
+                          v3(Frep[T::pt_rep(i)][0], Frep[T::pt_rep(i)][1], Frep[T::pt_rep(i)][2]));
         }
     }
 
