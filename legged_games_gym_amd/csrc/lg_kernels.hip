@@ -63,7 +63,7 @@ struct KArgs {                 // passed by value: lives in the kernarg segment 
 };
 
 // ------------------------------------------------------------------ section profiler (debug builds: -DLG_PROFILE)
-#define LG_NPROF 16
+#define LG_NPROF 20
 #ifdef LG_PROFILE
 // lane 0 of each workgroup accumulates s_memtime deltas per section in LDS and adds them to A.prof at the end.
 // idx < 0 starts the clock; slot 14 = whole kernel (s_memtime), slot 15 = whole kernel on the 100 MHz wall clock.
@@ -76,7 +76,8 @@ __device__ __forceinline__ void lg_prof(int idx, unsigned long long *out) {
         else acc[idx] += t - prev;
         if (out) {
             acc[14] = t - t0; acc[15] = wall_clock64() - w0;
-            for (int i = 0; i < LG_NPROF; i++) atomicAdd(out + i, acc[i]);
+            for (int i = 0; i < 16; i++) atomicAdd(out + i, acc[i]);
+            atomicMax(out + 16, acc[14]);                        // slowest workgroup of any launch since the last reset
         }
         prev = __builtin_readcyclecounter();
     }
@@ -1438,7 +1439,7 @@ const char *lg_last_error(void) { return g_err; }
 int lg_abi_version(void) { return LG_ABI_VERSION; }
 #ifdef LG_PROFILE
 // debug builds only (not part of legged_hip.h): copy out and optionally clear the k_step section accumulators
-int lg_debug_profile(lg_sim *s, unsigned long long *out16, int reset) {
+int lg_debug_profile(lg_sim *s, unsigned long long *out16 /* [LG_NPROF] */, int reset) {
     if (!s || !s->d_prof) return -1;
     if (hipDeviceSynchronize() != hipSuccess) return -2;
     if (hipMemcpy(out16, s->d_prof, sizeof(unsigned long long) * LG_NPROF, hipMemcpyDeviceToHost) != hipSuccess) return -2;

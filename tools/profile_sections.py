@@ -30,7 +30,7 @@ args = get_args(["--task", task, "--num_envs", str(n), "--headless", "--sim_devi
 env, cfg = task_registry.make_env(task, args)
 lib = capi.load_library()
 lib.lg_debug_profile.argtypes, lib.lg_debug_profile.restype = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int], ctypes.c_int
-out = (ctypes.c_uint64 * 16)()
+out = (ctypes.c_uint64 * 20)()
 g = torch.Generator(device="cuda").manual_seed(0)
 for _ in range(50):
     env.step(torch.randn(env.num_envs, env.num_actions, device="cuda", generator=g))
@@ -51,4 +51,5 @@ print(f"{task} N={env.num_envs}: {t0.elapsed_time(t1) / steps * 1e3:.1f} us per 
 for i, name in enumerate(NAMES):
     c = v[i] / wgs
     print(f"  {name:45s} {c:9.0f} cyc  {c / tot * 100:5.1f} %  {c / tot * wall / 1e3:6.2f} us")
+print(f"  slowest workgroup of any launch: {v[16]} cycles = {v[16] / (tot / wall) / 1e3:.1f} us (the kernel ends when it does)")
 print(f"  {'(unattributed)':45s} {tot - sum(v[:14]) / wgs:9.0f} cyc")
