@@ -464,8 +464,8 @@ LG_DEV float sample_height(const KArgs &A, const float *root, const float *qy, i
 // sampling (before the reset decision) and the observation (after it, Q7).  All 3*4*NCH gathers are issued before the
 // first one is consumed (the samples are L2-resident but ~1 us away for a lone wave).
 #define LG_STEP_WAVES 4
-template <class T> struct HeightCrew {
-    static constexpr int NV = T::K * LG_STEP_WAVES;
+template <class T, int NW = LG_STEP_WAVES> struct HeightCrew {
+    static constexpr int NV = T::K * NW;
     static constexpr int NCH = ((LG_MAX_HEIGHT_POINTS + 3) / 4 + NV - 1) / NV;     // chunks per thread: 3 (K = 4) / 6 (K = 2)
     float h[NCH][4];
 
@@ -723,7 +723,7 @@ struct EpisodeSums {
     }
 };
 
-template <class T, bool NET, bool HF> struct HelperWave {
+template <class T, bool NET, bool HF, int NW> struct HelperWave {
     // wave = 1 .. LG_STEP_WAVES-1; with the actuator net also the LSTM of joint (wave - 1); all 64 lanes active
     static LG_DEV void run(const KArgs &A, int wave, int lane, int e, int k, int d0, bool live, int64_t step,
                            float2 (*lds_x)[LG_BLOCK], float (*lds_tau)[LG_BLOCK], StepShared &sh) {
@@ -752,7 +752,7 @@ template <class T, bool NET, bool HF> struct HelperWave {
             }
         }
         __syncthreads();                                           // P1: final poses published
-        HeightCrew<T> hc;
+        HeightCrew<T, NW> hc;
         float hs = 0.0f;
         if (P.measure_heights) hs = hc.template sample<HF>(A, e, k + T::K * wave, live, sh.pose[lane][0], sh.pose[lane][1], sh.pose[lane][2], sh.pose[lane][3], sh.pose[lane][4]);
         sh.hsum[wave][lane] = hs;
@@ -784,10 +784,13 @@ template <class T, bool NET, bool HF> struct HelperWave {
 
 // POL: the flat actor (48-128-64-32) runs first on the same four waves (lg_policy.h) and hands the sampled actions over
 // in LDS -- one launch per rollout step instead of policy kernel + step kernel.
-template <class T, bool NET, bool HF, bool POL = false>
-__global__ void __launch_bounds__(LG_STEP_WAVES * LG_BLOCK) k_step(const KArgs A) {
-    static_assert(!NET || 1 + T::L == LG_STEP_WAVES, "one actuator wave per joint of the limb");
-    static_assert(!POL || (NET && LG_STEP_WAVES == LG_POLICY_WAVES && T::K * T::L <= 16), "fused policy needs the four-wave actuator-net kernel");
+// NW = waves per workgroup (1 rigid-body wave + NW-1 helpers).  Every wave of the kernel gets the rigid-body wave's 512
+// registers, so a CU holds NW waves = one workgroup at a time: the host picks the largest NW in {4, 2, 1} that still fits
+// all workgroups on the chip in one round (256 workgroups -> 4; Cassie at 8192 envs = 512 workgroups -> 2).
+template <class T, bool NET, bool HF, bool POL = false, int NW = LG_STEP_WAVES>
+__global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
+    static_assert(!NET || (NW == LG_STEP_WAVES && 1 + T::L == NW), "one actuator wave per joint of the limb");
+    static_assert(!POL || (NET && NW == LG_POLICY_WAVES && T::K * T::L <= 16), "fused policy needs the four-wave actuator-net kernel");
     constexpr int K = T::K, L = T::L, ND = K * L, NREP = T::NREP;
     const lg_params &P = A.P;
     const lg_buffers &B = A.B;
@@ -817,7 +820,7 @@ __global__ void __launch_bounds__(LG_STEP_WAVES * LG_BLOCK) k_step(const KArgs A
         __syncthreads();
     }
     if (wave > 0) {
-        HelperWave<T, NET, HF>::run(A, wave, lane, e, k, d0, live, step, lds_x, lds_tau, sh);
+        HelperWave<T, NET, HF, NW>::run(A, wave, lane, e, k, d0, live, step, lds_x, lds_tau, sh);
     } else {
     // ---- load persistent state (read once per env-step)
     float root[13], q[L], qd[L], act[L], tau[L];
@@ -887,12 +890,13 @@ __global__ void __launch_bounds__(LG_STEP_WAVES * LG_BLOCK) k_step(const KArgs A
     // _get_heights :831-869, by all four waves (HeightCrew); this wave is virtual lane k of its env
     sh.pose[lane][0] = root[0]; sh.pose[lane][1] = root[1]; sh.pose[lane][2] = root[2]; sh.pose[lane][3] = root[5]; sh.pose[lane][4] = root[6];
     __syncthreads();                                               // P1
-    HeightCrew<T> hc;
+    HeightCrew<T, NW> hc;
     float hsum = 0.0f;
     if (P.measure_heights) hsum = hc.template sample<HF>(A, e, k, live, root[0], root[1], root[2], root[5], root[6]);
     sh.hsum[0][lane] = hsum;
     __syncthreads();                                               // P2
-    hsum = (sh.hsum[0][lane] + sh.hsum[1][lane]) + (sh.hsum[2][lane] + sh.hsum[3][lane]);
+    if (NW == 4) hsum = (sh.hsum[0][lane] + sh.hsum[1][lane]) + (sh.hsum[2][lane] + sh.hsum[3][lane]);
+    else if (NW == 2) hsum = sh.hsum[0][lane] + sh.hsum[1][lane];
     if (P.push_interval > 0 && step % P.push_interval == 0) {                     // _push_robots :438-444
         float u[4];
         rand4(P.seed, e, step, RNG_PUSH, 0, u);
@@ -1022,6 +1026,7 @@ __global__ void __launch_bounds__(LG_STEP_WAVES * LG_BLOCK) k_step(const KArgs A
 
     sh.rst[lane] = reset ? 1 : 0; sh.root_z[lane] = root[2];
     __syncthreads();                                               // P3: helpers write the height observations / actuator state
+    if (NW == 1 && live && k == 0) { EpisodeSums es; es.load(A, e); es.update(A, e, lane, sh); }   // no helper wave: keep the sums here
 
     LG_PROF(12);
     // compute_observations :130 (stale base-frame quantities for reset envs, as in the reference)
@@ -1266,6 +1271,7 @@ struct lg_sim {
     float         *d_weights;
     unsigned int  *d_done;
     unsigned long long *d_prof;
+    int            num_cus;
 };
 
 template <class T> static int check_topology(const lg_robot_model *m) {
@@ -1470,6 +1476,7 @@ int lg_create(const lg_params *params, const lg_robot_model *model, const float 
     s->has_net = actuator_weights != nullptr; s->d_weights = nullptr; s->d_limb_table = nullptr; s->d_done = nullptr; s->d_prof = nullptr;
     if (hipMalloc(&s->d_done, sizeof(unsigned int)) != hipSuccess || hipMemset(s->d_done, 0, sizeof(unsigned int)) != hipSuccess) { delete s; return fail(-10, "hipMalloc failed"); }
     memset(&s->B, 0, sizeof s->B);
+    { hipDeviceProp_t prop; s->num_cus = (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256; }
 #ifdef LG_PROFILE
     if (hipMalloc(&s->d_prof, sizeof(unsigned long long) * LG_NPROF) != hipSuccess || hipMemset(s->d_prof, 0, sizeof(unsigned long long) * LG_NPROF) != hipSuccess) { delete s; return fail(-10, "hipMalloc failed"); }
 #endif
@@ -1525,6 +1532,13 @@ int lg_set_params(lg_sim *s, const lg_params *p) {
     return upload_tables(s);
 }
 
+// helper waves only pay off while every workgroup still gets a CU of its own in one round (all waves carry 512 registers)
+static int waves_for(unsigned workgroups, int num_cus) { return workgroups <= (unsigned)num_cus ? 4 : (workgroups <= 2u * num_cus ? 2 : 1); }
+#define LAUNCH_NW(TRAITS, HFV)                                                                                                   \
+    { if (nw == 4) hipLaunchKernelGGL((k_step<TRAITS, false, HFV, false, 4>), g, dim3(4 * LG_BLOCK), 0, st, a);                  \
+      else if (nw == 2) hipLaunchKernelGGL((k_step<TRAITS, false, HFV, false, 2>), g, dim3(2 * LG_BLOCK), 0, st, a);             \
+      else hipLaunchKernelGGL((k_step<TRAITS, false, HFV, false, 1>), g, dim3(LG_BLOCK), 0, st, a); }
+
 int lg_step(lg_sim *s, const float *actions, int64_t common_step_counter, void *stream) {
     if (!s || !s->bound) return fail(-8, "lg_bind has not been called");
     if (!actions) return fail(-1, "null actions");
@@ -1535,14 +1549,16 @@ int lg_step(lg_sim *s, const float *actions, int64_t common_step_counter, void *
     const bool net = s->P.control_type == LG_CTRL_ACTUATOR_NET;
     if (s->kind == ROBOT_ANYMAL) {
         dim3 g(grid_for<AnymalTraits>(s->P.num_envs)), b(LG_STEP_WAVES * LG_BLOCK);
+        const int nw = net ? LG_STEP_WAVES : waves_for(g.x, s->num_cus);
         if (net && !hf) hipLaunchKernelGGL((k_step<AnymalTraits, true, false>), g, b, 0, st, a);
         else if (net && hf) hipLaunchKernelGGL((k_step<AnymalTraits, true, true>), g, b, 0, st, a);
-        else if (!net && !hf) hipLaunchKernelGGL((k_step<AnymalTraits, false, false>), g, b, 0, st, a);
-        else hipLaunchKernelGGL((k_step<AnymalTraits, false, true>), g, b, 0, st, a);
+        else if (!hf) LAUNCH_NW(AnymalTraits, false)
+        else LAUNCH_NW(AnymalTraits, true)
     } else {
-        dim3 g(grid_for<CassieTraits>(s->P.num_envs)), b(LG_STEP_WAVES * LG_BLOCK);
-        if (!hf) hipLaunchKernelGGL((k_step<CassieTraits, false, false>), g, b, 0, st, a);
-        else hipLaunchKernelGGL((k_step<CassieTraits, false, true>), g, b, 0, st, a);
+        dim3 g(grid_for<CassieTraits>(s->P.num_envs));
+        const int nw = waves_for(g.x, s->num_cus);
+        if (!hf) LAUNCH_NW(CassieTraits, false)
+        else LAUNCH_NW(CassieTraits, true)
     }
     HIP_TRY(hipGetLastError());
     return 0;

@@ -193,6 +193,23 @@ def test_full_step_parity(task, plane):
         assert ok.mean() > 0.95 and np.median(err) < 2e-3 and np.quantile(err, 0.9) < 2e-2, (ok.mean(), np.median(err), np.quantile(err, 0.9))
 
 
+@pytest.mark.parametrize("task,N", [("cassie", 8200), ("cassie", 16500), ("a1", 8200)])
+def test_step_parity_with_fewer_helper_waves(task, N):
+    """More than one workgroup per CU: lg_step drops to 2 (<= 512 workgroups) or 1 (> 512) waves per workgroup; the helper
+    work (height crew, episode sums) moves accordingly.  One policy step against the oracle on every env."""
+    cfg, robot, p, names, o, d = pair(task, N)
+    init_both(o, d, N)
+    g = torch.Generator().manual_seed(5)
+    act = (torch.randn(N, 12, generator=g) * 0.3).float()
+    o.step(act.numpy(), 1); d.step(act.cuda(), 1)
+    q_o, q_d = o.buf["dof_state"].reshape(N, 12, 2), get(d, "dof_state").reshape(N, 12, 2)
+    assert np.abs(q_o[..., 0] - q_d[..., 0]).max() < 2e-4
+    assert np.abs(o.buf["root_states"][:, :7] - get(d, "root_states")[:, :7]).max() < 2e-4
+    assert np.array_equal(o.buf["reset_buf"], get(d, "reset_buf"))
+    assert maxdiff(o, d, "rew_buf") < 2e-4 and maxdiff(o, d, "obs_buf") < 5e-3
+    assert maxdiff(o, d, "episode_sums") < 2e-4 and maxdiff(o, d, "episode_length_buf") == 0
+
+
 def _rough_terrain(N):
     from legged_games_gym_amd.utils.terrain import Terrain
     from legged_games_gym_amd.envs import configs
