@@ -258,8 +258,6 @@ LG_DEV void swap32(float &a, float &b) {        // a <- [a.lo | b.lo], b <- [a.h
     auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
     a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
 }
-LG_DEV float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.442695041f * x)); }
-LG_DEV float fast_tanh(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.885390082f * x)) - 1.0f; }
 // packed-fp32 pairs (v_pk_add/mul/fma_f32): two hidden units per instruction; exp2 / rcp stay per component
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define LSTM_EXP_CAP 0x1p30f   // sigma saturates at 9e-10 and a product of three (1 + e) terms stays far below FLT_MAX

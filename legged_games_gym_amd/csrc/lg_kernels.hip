@@ -91,7 +91,8 @@ __device__ __forceinline__ void lg_prof(int idx, unsigned long long *out) {
 #define LG_PROF_BEGIN()
 #define LG_PROF_END(i, out)
 #endif
-enum { PF_PROLOGUE = 0, PF_TORQUE, PF_KINEMATICS, PF_INWARD, PF_BASE, PF_OUTWARD, PF_INTEGRATE, PF_POST, PF_EXTRAS };
+enum { PF_PROLOGUE = 0, PF_TORQUE, PF_KINEMATICS, PF_INWARD, PF_BASE, PF_OUTWARD, PF_INTEGRATE, PF_POST, PF_EXTRAS,
+       PF_POST_HEIGHTS, PF_POST_TERMS, PF_POST_REWARD, PF_POST_RESET, PF_POST_OBS };
 
 // ------------------------------------------------------------------ terrain
 // Split in two so the four samples of EVERY collision point of a sub-step are in flight before the first is consumed
@@ -126,10 +127,6 @@ template <bool HF> LG_DEV void hf_eval(const KArgs &A, const HfFetch &f, float &
     float l = 1.0f / sqrtf(dhdx * dhdx + dhdy * dhdy + 1.0f);
     n = v3(-dhdx * l, -dhdy * l, l);
 }
-template <bool HF> LG_DEV void ground_query(const KArgs &A, float x, float y, float &h, V3 &n) {
-    hf_eval<HF>(A, hf_fetch<HF>(A, x, y), h, n);
-}
-
 // ------------------------------------------------------------------ one 5 ms rigid-body step for (env, limb)
 struct Contact { V3 r, n, vc, f, fs; float depth, bt, vtn; bool on; };   // fs: constant sliding force of the corrector pass
 
@@ -445,19 +442,6 @@ LG_DEV float wrap_to_pi(float a) {                                              
     if (a > pi) a -= two_pi;
     return a;
 }
-LG_DEV float sample_height(const KArgs &A, const float *root, const float *qy, int i) {                  // :831-869, one point
-    const lg_params &P = A.P;
-    V3 p = quat_apply(qy, v3(P.height_points[i][0], P.height_points[i][1], 0.0f));
-    float px = p.x + root[0] + P.hf_border, py = p.y + root[1] + P.hf_border;
-    long ix = (long)(px / P.hf_horizontal_scale), iy = (long)(py / P.hf_horizontal_scale);
-    ix = ix < 0 ? 0 : ix; ix = ix > P.hf_rows - 2 ? P.hf_rows - 2 : ix;
-    iy = iy < 0 ? 0 : iy; iy = iy > P.hf_cols - 2 ? P.hf_cols - 2 : iy;
-    const int16_t *H = A.B.height_samples;
-    int16_t h1 = H[ix * P.hf_cols + iy], h2 = H[(ix + 1) * P.hf_cols + iy], h3 = H[ix * P.hf_cols + iy + 1];
-    int16_t h = h1 < h2 ? h1 : h2; h = h < h3 ? h : h3;
-    return (float)h * P.hf_vertical_scale;
-}
-
 // _get_heights (:831-869) and the height part of compute_observations (:224-226) for the fused step, spread over ALL waves
 // of the workgroup: an env's chunks (4 points = one Philox block each) are dealt to K * LG_STEP_WAVES "virtual lanes";
 // thread (wave, lane = (env, limb k)) is virtual lane k + K * wave and keeps its chunks' heights in registers between
@@ -912,7 +896,7 @@ __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
         for (int r = 0; r < NREP; r++) { cf[3 * r] = Frep[r][0]; cf[3 * r + 1] = Frep[r][1]; cf[3 * r + 2] = Frep[r][2]; }
         if (k == 0) { float *c0 = B.contact_forces + (size_t)e * (1 + K * NREP) * 3; c0[0] = Fbase[0]; c0[1] = Fbase[1]; c0[2] = Fbase[2]; }
     }
-    LG_PROF(9);
+    LG_PROF(PF_POST_HEIGHTS);
     // check_termination :139-145
     int term_local = 0;
     float coll_local = 0.0f;
@@ -998,7 +982,7 @@ __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
         term[LG_REW_TRACKING_LIN_VEL] = __expf(-(ex * ex + ey * ey) / P.tracking_sigma);
         term[LG_REW_TRACKING_ANG_VEL] = __expf(-(ew * ew) / P.tracking_sigma);
     }
-    LG_PROF(10);
+    LG_PROF(PF_POST_TERMS);
     float rew = 0.0f;
     const bool writer = live && k == 0;
     float r_t[LG_NUM_REWARD_TERMS];                     // scaled terms; exactly 0 for disabled ones (x + 0 == x: the sum order is the oracle's)
@@ -1011,7 +995,7 @@ __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
 #pragma unroll
     for (int t = 0; t < LG_NUM_REWARD_TERMS; t++) sh.r_t[t][lane] = r_t[t];       // episode sums: helper wave, after P3
 
-    LG_PROF(11);
+    LG_PROF(PF_POST_REWARD);
     // reset_idx for terminated envs (predicated epilogue) :128-129, anymal.py:56-60
     float origin[3] = {B.env_origins[(size_t)e * 3], B.env_origins[(size_t)e * 3 + 1], B.env_origins[(size_t)e * 3 + 2]};
     if (reset) {
@@ -1028,12 +1012,12 @@ __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
     __syncthreads();                                               // P3: helpers write the height observations / actuator state
     if (NW == 1 && live && k == 0) { EpisodeSums es; es.load(A, e); es.update(A, e, lane, sh); }   // no helper wave: keep the sums here
 
-    LG_PROF(12);
+    LG_PROF(PF_POST_RESET);
     // compute_observations :130 (stale base-frame quantities for reset envs, as in the reference)
     write_observations<T>(A, e, k, live, step, root, q, qd, act, tab, blv, bav, pg, cmd, false);
     if (P.measure_heights) hc.write_obs(A, e, k, live, step, root[2]);
 
-    LG_PROF(13);
+    LG_PROF(PF_POST_OBS);
     // ---- write persistent state back (written once per env-step)
     if (live) {
 #pragma unroll
