@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LG_ABI_VERSION        9
+#define LG_ABI_VERSION        10
 
 #define LG_MAX_LIMBS          4
 #define LG_MAX_CHAIN          6
@@ -212,6 +212,13 @@ int  lg_policy_act(lg_policy *p, const float *obs, float *actions, float *mean, 
  * the caller uses lg_policy_act + lg_step (reference: ActorCritic.act + LeggedRobot.step, legged_robot.py:80-104). */
 int  lg_step_policy(lg_sim *sim, lg_policy *p, const float *obs, float *actions, float *mean, uint64_t seed,
                     int32_t deterministic, int64_t common_step_counter, void *stream);
+
+/* GAE(gamma, lambda) scan over a rollout, one thread per env (rsl_rl RolloutStorage.compute_returns, [EXTERNAL]; hyper-
+ * parameters legged_robot_config.py:222-223).  rewards, values, returns, advantages: float [T, N]; dones: uint8 [T, N];
+ * last_values: float [N].  returns[t] = A_t + V_t with A_t = delta_t + gamma lam (1 - done_t) A_{t+1}; advantages = returns -
+ * values (un-normalised: the caller normalises over the global batch).  Device pointers, asynchronous on `stream`. */
+int  lg_gae_returns(const float *rewards, const float *values, const uint8_t *dones, const float *last_values, float gamma, float lam,
+                    float *returns, float *advantages, int32_t num_steps, int32_t num_envs, void *stream);
 
 const char *lg_last_error(void);
 int  lg_abi_version(void);

@@ -1425,6 +1425,34 @@ int lg_policy_act(lg_policy *p, const float *obs, float *actions, float *mean, i
     return 0;
 }
 
+// ------------------------------------------------------------------ GAE scan (PPO rollout post-processing)
+__global__ void __launch_bounds__(256) k_gae(const float *__restrict__ rewards, const float *__restrict__ values, const uint8_t *__restrict__ dones,
+                                             const float *__restrict__ last_values, float gamma, float lam, float *__restrict__ returns,
+                                             float *__restrict__ advantages, int T, int N) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N) return;
+    float adv = 0.0f, nxt = last_values[e];
+    for (int t = T - 1; t >= 0; t--) {                 // coalesced across envs at every t
+        const size_t i = (size_t)t * N + e;
+        const float v = values[i], nd = 1.0f - (float)dones[i];
+        const float delta = rewards[i] + nd * gamma * nxt - v;
+        adv = delta + nd * gamma * lam * adv;
+        returns[i] = adv + v;
+        advantages[i] = (adv + v) - v;                 // = returns - values, as the reference computes it
+        nxt = v;
+    }
+}
+
+int lg_gae_returns(const float *rewards, const float *values, const uint8_t *dones, const float *last_values, float gamma, float lam,
+                   float *returns, float *advantages, int32_t num_steps, int32_t num_envs, void *stream) {
+    if (!rewards || !values || !dones || !last_values || !returns || !advantages) return fail(-1, "null argument");
+    if (num_steps <= 0 || num_envs <= 0) return 0;
+    hipLaunchKernelGGL(k_gae, dim3((num_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, rewards, values, dones, last_values, gamma, lam,
+                       returns, advantages, num_steps, num_envs);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 const char *lg_last_error(void) { return g_err; }
 int lg_abi_version(void) { return LG_ABI_VERSION; }
 #ifdef LG_PROFILE

@@ -51,6 +51,33 @@ class RolloutStorage:
     def compute_returns(self, last_values, gamma, lam):
         """GAE(gamma, lambda); advantages normalised over the GLOBAL batch: with several ranks
         the fused [returns || advantages] buffer is all-gathered once (RCCL over xGMI)."""
+        if self._gae_kernel(last_values, gamma, lam):
+            pass
+        else:
+            self._gae_torch(last_values, gamma, lam)
+        self._normalise_advantages()
+
+    def _gae_kernel(self, last_values, gamma, lam):
+        """One launch of the HIP scan (``lg_gae_returns``) instead of ~6 torch kernels per rollout step; GPU only."""
+        if not self.values.is_cuda:
+            return False
+        if getattr(self, "_lib", None) is None:
+            try:
+                from .. import capi
+                self._lib = capi.load_library()
+            except Exception:                      # rl/ stays usable without the extension (plain rsl_rl semantics)
+                self._lib = False
+        if not self._lib:
+            return False
+        T, N = self.num_transitions_per_env, self.num_envs
+        lv = last_values.reshape(-1).contiguous().float()
+        rc = self._lib.lg_gae_returns(self.rewards.data_ptr(), self.values.data_ptr(), self.dones.data_ptr(), lv.data_ptr(), float(gamma), float(lam),
+                                      self.returns.data_ptr(), self.advantages.data_ptr(), T, N, torch.cuda.current_stream(self.values.device).cuda_stream)
+        if rc != 0:
+            raise RuntimeError(f"lg_gae_returns failed ({rc}): {self._lib.lg_last_error().decode()}")
+        return True
+
+    def _gae_torch(self, last_values, gamma, lam):
         adv = 0
         for step in reversed(range(self.num_transitions_per_env)):
             nxt = last_values if step == self.num_transitions_per_env - 1 else self.values[step + 1]
@@ -59,6 +86,8 @@ class RolloutStorage:
             adv = delta + not_done * gamma * lam * adv
             self.returns[step] = adv + self.values[step]
         torch.sub(self.returns, self.values, out=self.advantages)        # in place: a captured update graph reads this buffer
+
+    def _normalise_advantages(self):
         if _world() > 1:
             fused = torch.cat((self.returns.flatten(), self.advantages.flatten()))
             gathered = torch.empty(_world() * fused.numel(), device=fused.device, dtype=fused.dtype)
@@ -77,10 +106,11 @@ class RolloutStorage:
         lens = idx[1:] - idx[:-1]
         return lens.float().mean(), self.rewards.mean()
 
-    def mini_batch_generator(self, num_mini_batches, num_epochs=8):
+    def mini_batch_generator(self, num_mini_batches, num_epochs=8, perm=None):
         B = self.num_envs * self.num_transitions_per_env
         mb = B // num_mini_batches
-        perm = torch.randperm(num_mini_batches * mb, requires_grad=False, device=self.device)
+        if perm is None:
+            perm = torch.randperm(num_mini_batches * mb, requires_grad=False, device=self.device)
         obs = self.observations.flatten(0, 1)
         cobs = self.privileged_observations.flatten(0, 1) if self.privileged_observations is not None else obs
         act, val, ret = self.actions.flatten(0, 1), self.values.flatten(0, 1), self.returns.flatten(0, 1)
@@ -100,7 +130,7 @@ class PPO:
         # Single-GPU runs replay one captured HIP graph per mini-batch step (forward, losses, backward, grad clip, Adam and
         # the adaptive-KL learning rate all on the device): the flat networks' update is launch-bound (~150 tiny kernels).
         self._graph_ok = bool(graphed_update) and str(device).startswith("cuda")
-        self._graph = None
+        self._graph, self._graph_key = None, None
         self._updates_done = 0
         self.desired_kl, self.schedule, self.learning_rate = desired_kl, schedule, learning_rate
         self.actor_critic = actor_critic.to(device)
@@ -215,11 +245,15 @@ class PPO:
             self._acc[0] += vloss.detach()
             self._acc[1] += surrogate.detach()
 
-    def _update_graphed(self):
+    def _update_graphed(self, perm=None):
         st = self.storage
         B = st.num_envs * st.num_transitions_per_env
         mb = B // self.num_mini_batches
-        if self._graph is None:
+        key = (st.observations.data_ptr(), st.advantages.data_ptr(), st.returns.data_ptr(), mb)
+        if self._graph is not None and key != self._graph_key:
+            self._graph = None                      # the storage was re-allocated: the captured graph reads the old buffers
+        self._graph_key = key
+        if self._graph is None and (not hasattr(self, "_ix") or self._ix.numel() != mb):
             self._ix = torch.zeros(mb, dtype=torch.int64, device=self.device)
             self._acc = torch.zeros(2, device=self.device)
         self._acc.zero_()
@@ -229,8 +263,9 @@ class PPO:
             self._gstream = torch.cuda.Stream(device=self.device)
         capture_now = self._graph is None and self._updates_done >= 1
         cur = torch.cuda.current_stream(self.device)
-        for _ in range(self.num_learning_epochs):
+        if perm is None:                             # one permutation per update, re-used by every epoch (rsl_rl)
             perm = torch.randperm(self.num_mini_batches * mb, device=self.device)
+        for _ in range(self.num_learning_epochs):
             for i in range(self.num_mini_batches):
                 self._ix.copy_(perm[i * mb:(i + 1) * mb])
                 if self._graph is not None:
@@ -257,11 +292,12 @@ class PPO:
         st.clear()
         return mean_v, mean_s
 
-    def update(self):
+    def update(self, perm=None):
+        """One PPO update over the stored rollout.  ``perm`` (optional) fixes the mini-batch permutation (tests)."""
         if self._graph_ok and _world() == 1:
-            return self._update_graphed()
+            return self._update_graphed(perm)
         mean_v, mean_s = 0.0, 0.0
-        gen = self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs)
+        gen = self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs, perm)
         for obs, cobs, act, tval, adv, ret, old_lp, old_mu, old_sig, _, _ in gen:
             self.actor_critic.act(obs)
             lp = self.actor_critic.get_actions_log_prob(act)
