@@ -199,6 +199,9 @@ class LeggedRobot(BaseTask):
                                       replace_cylinder_with_capsule=cfg.asset.replace_cylinder_with_capsule) \
             if os.path.isfile(asset_path) else load_model(asset_path)
         rm = self.robot_model
+        if int(getattr(cfg.asset, "self_collisions", 1)) == 0 and not getattr(LeggedRobot, "_warned_self_collision", False):
+            LeggedRobot._warned_self_collision = True     # e.g. anymal_c_flat (anymal_c_flat_config.py:42); DESIGN.md section 3, known limits
+            print("[legged_games_gym_amd] asset.self_collisions = 0 (enabled) is not modelled by this engine: links of one robot do not collide with each other")
         self.num_dof = self.num_dofs = rm.num_dof
         self.num_bodies = rm.num_bodies
         self.dof_names = list(rm.dof_names)
