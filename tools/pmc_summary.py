@@ -16,7 +16,7 @@ def short(name):
             return name.split("(")[0].replace("void ", "").replace("lg::", "")
     return None
 
-stats = glob.glob(os.path.join(SRC, "stats", "*", "*_kernel_stats.csv"))[0]
+stats = max(glob.glob(os.path.join(SRC, "stats", "*", "*_kernel_stats.csv")), key=os.path.getmtime)   # gpurun merges: keep the newest run
 rows = list(csv.reader(open(stats)))
 with open(os.path.join(DST, f"{tag}_bench_kernel_stats.csv"), "w", newline="") as fh:
     w = csv.writer(fh)
@@ -27,7 +27,7 @@ per = {}
 for d in sorted(glob.glob(os.path.join(SRC, "pmc_*"))):
     if not os.path.isdir(d):
         continue
-    for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+    for f in [max(glob.glob(os.path.join(d, "*", "*_counter_collection.csv")), key=os.path.getmtime)]:
         for r in csv.DictReader(open(f)):
             k = short(r["Kernel_Name"])
             if k is None:
