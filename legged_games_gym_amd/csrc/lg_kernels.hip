@@ -182,42 +182,82 @@ LG_DEV V3 clamp_norm(V3 a, float lim) {           // asset.max_linear/angular_ve
     return a;
 }
 
+// rigid-body inertia about the body's own reference point and bias force (gyroscopic - gravity), world axes
+LG_DEV void body_terms(V3 grav, float m, V3 com_l, const float *Il, const M3 &R, V3 w, V3 v, AI &I0, S6 &p0) {
+    V3 c = mul(R, com_l);
+    M3 Ilf; Ilf.m[0] = Il[0]; Ilf.m[1] = Il[1]; Ilf.m[2] = Il[2]; Ilf.m[3] = Il[1]; Ilf.m[4] = Il[3]; Ilf.m[5] = Il[4];
+    Ilf.m[6] = Il[2]; Ilf.m[7] = Il[4]; Ilf.m[8] = Il[5];
+    M3 Rt;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j2 = 0; j2 < 3; j2++) Rt.m[3 * i + j2] = R.m[3 * j2 + i];
+    M3 Ic = mul(mul(R, Ilf), Rt);
+#pragma unroll
+    for (int i = 0; i < 9; i++) I0.H[i] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 6; i++) I0.M[i] = 0.0f;
+    I0.A[0] = Ic.m[0]; I0.A[1] = Ic.m[1]; I0.A[2] = Ic.m[2]; I0.A[3] = Ic.m[4]; I0.A[4] = Ic.m[5]; I0.A[5] = Ic.m[8];
+    ai_add_point(I0, m, c);
+    V3 l = (v + cross(w, c)) * m;
+    V3 n = mul(Ic, w) + cross(c, l);
+    V3 fg = grav * m;
+    p0.w = (cross(w, n) + cross(v, l)) - cross(c, fg);
+    p0.v = cross(w, l) - fg;
+}
+// one joint of the forward-kinematics chain (world axes): parent frame (Rpar, wpar, vpar) -> this body's frame
+struct FkOut { M3 R; V3 db, ax, w, v; };
+LG_DEV FkOut fk_joint(const float *tj, const M3 &Rpar, V3 wpar, V3 vpar, float q, float qd) {
+    FkOut o;
+    o.db = mul(Rpar, v3(tj[J_POS], tj[J_POS + 1], tj[J_POS + 2]));
+    M3 Rfix;
+#pragma unroll
+    for (int i = 0; i < 9; i++) Rfix.m[i] = tj[J_ROT + i];
+    const M3 Rz = mul(Rpar, Rfix);
+    o.ax = mul(Rz, v3(tj[J_AXIS], tj[J_AXIS + 1], tj[J_AXIS + 2]));
+    float sn, cs;
+    __sincosf(q, &sn, &cs);               // v_sin/v_cos (|q| stays within a few rad; abs err ~1e-6)
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        V3 col = v3(Rz.m[c], Rz.m[3 + c], Rz.m[6 + c]);
+        V3 rot = (col * cs + cross(o.ax, col) * sn) + o.ax * (dot(o.ax, col) * (1.0f - cs));
+        o.R.m[c] = rot.x; o.R.m[3 + c] = rot.y; o.R.m[6 + c] = rot.z;
+    }
+    o.w = wpar + o.ax * qd;
+    o.v = vpar + cross(wpar, o.db);
+    return o;
+}
+// LDS hand-over of the limb bodies' (I0, p0) when the helper waves compute them (k_step, quadruped kernels): 28 floats per
+// (joint, lane) as 7 float4.
+#define LG_BT_QUADS 7
+LG_DEV void bt_store(float4 (*dst)[LG_BLOCK], int lane, const AI &I, const S6 &p) {
+    dst[0][lane] = make_float4(I.A[0], I.A[1], I.A[2], I.A[3]); dst[1][lane] = make_float4(I.A[4], I.A[5], I.H[0], I.H[1]);
+    dst[2][lane] = make_float4(I.H[2], I.H[3], I.H[4], I.H[5]); dst[3][lane] = make_float4(I.H[6], I.H[7], I.H[8], I.M[0]);
+    dst[4][lane] = make_float4(I.M[1], I.M[2], I.M[3], I.M[4]); dst[5][lane] = make_float4(I.M[5], p.w.x, p.w.y, p.w.z);
+    dst[6][lane] = make_float4(p.v.x, p.v.y, p.v.z, 0.0f);
+}
+LG_DEV void bt_load(const float4 (*src)[LG_BLOCK], int lane, AI &I, S6 &p) {
+    float4 a = src[0][lane], b = src[1][lane], c = src[2][lane], d = src[3][lane], e = src[4][lane], f = src[5][lane], g = src[6][lane];
+    I.A[0] = a.x; I.A[1] = a.y; I.A[2] = a.z; I.A[3] = a.w; I.A[4] = b.x; I.A[5] = b.y; I.H[0] = b.z; I.H[1] = b.w;
+    I.H[2] = c.x; I.H[3] = c.y; I.H[4] = c.z; I.H[5] = c.w; I.H[6] = d.x; I.H[7] = d.y; I.H[8] = d.z; I.M[0] = d.w;
+    I.M[1] = e.x; I.M[2] = e.y; I.M[3] = e.z; I.M[4] = e.w; I.M[5] = f.x; p.w = v3(f.y, f.z, f.w); p.v = v3(g.x, g.y, g.z);
+}
+
 // `torques_ready` runs between the kinematics half (needs no torques) and the articulated-body passes: the fused step
 // uses it to join the actuator waves, which compute this sub-step's torques meanwhile (k_step).
 struct NoWait { LG_DEV void operator()() const {} };
-template <class T, bool HF, class Ready = NoWait>
+// OFFLOAD: the limb bodies' (I0, p0) are computed by the helper waves meanwhile and read from `bt` after `torques_ready`.
+template <class T, bool HF, class Ready = NoWait, bool OFFLOAD = false>
 LG_DEV void physics_substep(const KArgs &A, const float *tab, int lane_k, float (&root)[13], float (&q)[T::L], float (&qd)[T::L],
                             const float (&tau)[T::L], float base_mass, float mu,
-                            float (&Frep)[T::NREP][3], float (&Fbase)[3], Ready torques_ready = Ready()) {
+                            float (&Frep)[T::NREP][3], float (&Fbase)[3], Ready torques_ready = Ready(),
+                            const float4 (*bt)[LG_BT_QUADS][LG_BLOCK] = nullptr, float4 (*fkout)[4][LG_BLOCK] = nullptr,
+                            volatile int *fk_ready = nullptr, int substep_no = 0) {
     constexpr int K = T::K, L = T::L, NPT = T::NPT;
     const lg_params &P = A.P;
     const float dt = P.sim_dt;
     const V3 grav = v3(P.gravity[0], P.gravity[1], P.gravity[2]);
     const float kn = P.contact_stiffness * dt + P.contact_damping;
-
-    // rigid-body inertia about the body's own reference point and bias force (gyroscopic - gravity)
-    auto body_terms = [&](float m, V3 com_l, const float *Il, const M3 &R, V3 w, V3 v, AI &I0, S6 &p0) {
-        V3 c = mul(R, com_l);
-        M3 Ilf; Ilf.m[0] = Il[0]; Ilf.m[1] = Il[1]; Ilf.m[2] = Il[2]; Ilf.m[3] = Il[1]; Ilf.m[4] = Il[3]; Ilf.m[5] = Il[4];
-        Ilf.m[6] = Il[2]; Ilf.m[7] = Il[4]; Ilf.m[8] = Il[5];
-        M3 Rt;
-#pragma unroll
-        for (int i = 0; i < 3; i++)
-#pragma unroll
-            for (int j2 = 0; j2 < 3; j2++) Rt.m[3 * i + j2] = R.m[3 * j2 + i];
-        M3 Ic = mul(mul(R, Ilf), Rt);
-#pragma unroll
-        for (int i = 0; i < 9; i++) I0.H[i] = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 6; i++) I0.M[i] = 0.0f;
-        I0.A[0] = Ic.m[0]; I0.A[1] = Ic.m[1]; I0.A[2] = Ic.m[2]; I0.A[3] = Ic.m[4]; I0.A[4] = Ic.m[5]; I0.A[5] = Ic.m[8];
-        ai_add_point(I0, m, c);
-        V3 l = (v + cross(w, c)) * m;
-        V3 n = mul(Ic, w) + cross(c, l);
-        V3 fg = grav * m;
-        p0.w = (cross(w, n) + cross(v, l)) - cross(c, fg);
-        p0.v = cross(w, l) - fg;
-    };
 
     // ---- per body, fused: kinematics -> inertia / bias -> contact candidates.  World axes; each body's spatial
     // quantities live at ITS OWN joint origin O_j (DESIGN.md "Conditioning"): db = O_j - O_parent, wb = angular
@@ -234,7 +274,7 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, int lane_k, float 
         float sc = base_mass / A.base.mass, Il[6];
 #pragma unroll
         for (int i = 0; i < 6; i++) Il[i] = A.base.inertia[i] * sc;
-        body_terms(base_mass, v3(A.base.com[0], A.base.com[1], A.base.com[2]), Il, R0, w0, v0, I0b, p0b);
+        body_terms(grav, base_mass, v3(A.base.com[0], A.base.com[1], A.base.com[2]), Il, R0, w0, v0, I0b, p0b);
         // base collision points are split over the env's lanes (lane i owns point i); their inertia / bias contribution
         // joins the lane's limb contribution before the butterfly, their force is butterfly-summed afterwards
         static_assert(K <= LG_MAX_BASE_POINTS, "one base point per lane at most");
@@ -254,30 +294,29 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, int lane_k, float 
 #pragma unroll
         for (int j = 0; j < L; j++) {
             const float *tj = tab + j * LG_JS;
-            db[j] = mul(Rpar, v3(tj[J_POS], tj[J_POS + 1], tj[J_POS + 2]));
+            const FkOut fk = fk_joint(tj, Rpar, wpar, vpar, q[j], qd[j]);
+            db[j] = fk.db; ax[j] = fk.ax;
             const V3 rj = rpar + db[j];
-            M3 Rfix;
-#pragma unroll
-            for (int i = 0; i < 9; i++) Rfix.m[i] = tj[J_ROT + i];
-            const M3 Rz = mul(Rpar, Rfix);
-            ax[j] = mul(Rz, v3(tj[J_AXIS], tj[J_AXIS + 1], tj[J_AXIS + 2]));
-            float sn, cs;
-            __sincosf(q[j], &sn, &cs);               // v_sin/v_cos (|q| stays within a few rad; abs err ~1e-6)
-            M3 Rj;
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                V3 col = v3(Rz.m[c], Rz.m[3 + c], Rz.m[6 + c]);
-                V3 rot = (col * cs + cross(ax[j], col) * sn) + ax[j] * (dot(ax[j], col) * (1.0f - cs));
-                Rj.m[c] = rot.x; Rj.m[3 + c] = rot.y; Rj.m[6 + c] = rot.z;
-            }
-            const V3 wj = wpar + ax[j] * qd[j];
-            const V3 vj = vpar + cross(wpar, db[j]);
+            const M3 &Rj = fk.R;
+            const V3 wj = fk.w, vj = fk.v;
             C[j].w = cross(wj, ax[j]) * qd[j];
             C[j].v = cross(vj, ax[j]) * qd[j];
-            float Il[6];
+            if (!OFFLOAD) {
+                float Il[6];
 #pragma unroll
-            for (int i = 0; i < 6; i++) Il[i] = tj[J_INERTIA + i];
-            body_terms(tj[J_MASS], v3(tj[J_COM], tj[J_COM + 1], tj[J_COM + 2]), Il, Rj, wj, vj, I0[j], p0[j]);
+                for (int i = 0; i < 6; i++) Il[i] = tj[J_INERTIA + i];
+                body_terms(grav, tj[J_MASS], v3(tj[J_COM], tj[J_COM + 1], tj[J_COM + 2]), Il, Rj, wj, vj, I0[j], p0[j]);
+            } else {                                   // hand the body's frame to helper wave j (it computes I0[j], p0[j])
+                const int ln = threadIdx.x % LG_BLOCK;
+                fkout[j][0][ln] = make_float4(Rj.m[0], Rj.m[1], Rj.m[2], Rj.m[3]);
+                fkout[j][1][ln] = make_float4(Rj.m[4], Rj.m[5], Rj.m[6], Rj.m[7]);
+                fkout[j][2][ln] = make_float4(Rj.m[8], wj.x, wj.y, wj.z);
+                fkout[j][3][ln] = make_float4(vj.x, vj.y, vj.z, 0.0f);
+                if (j == L - 1) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (ln == 0) *fk_ready = substep_no;
+                }
+            }
 #pragma unroll
             for (int i = 0; i < NPT; i++) if (T::pt_joint(i) == j) {
                 const float *tp = tab + L * LG_JS + 4 * i;
@@ -306,6 +345,10 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, int lane_k, float 
 
     LG_PROF(PF_KINEMATICS);
     torques_ready();
+    if (OFFLOAD) {
+#pragma unroll
+        for (int j = 0; j < L; j++) bt_load(bt[j], threadIdx.x % LG_BLOCK, I0[j], p0[j]);
+    }
     LG_PROF(PF_TORQUE);
     // ---- articulated-body passes with the contact impedances folded in
     S6 U[L], acc0;
@@ -667,13 +710,18 @@ LG_DEV void finish_extras(const KArgs &A, int t, int64_t step_used, bool publish
 // of every lane (state resident in their registers for the whole step) and compute each sub-step's torques while wave 0
 // does the torque-independent kinematics half.  Hand-over through LDS (lds_x -> lds_tau), two barriers per sub-step.
 // Post-physics, every variant: the helper waves join the height sampling / height observations (HeightCrew), 4 x the lanes.
-struct StepShared {                                              // LDS hand-over between the rigid-body wave and the helpers
+template <bool OFF> struct StepSharedT {                         // LDS hand-over between the rigid-body wave and the helpers
     float pose[LG_BLOCK][5];                                     // x, y, z, q.z, q.w of the lane's env after the last sub-step
     float hsum[LG_STEP_WAVES][LG_BLOCK];                         // partial sums of (root z - height) per wave
     float root_z[LG_BLOCK];                                      // root z after the reset decision (observation input, Q7)
     int   rst[LG_BLOCK];                                         // reset flag of the lane's env
     float r_t[LG_NUM_REWARD_TERMS][LG_BLOCK];                    // this step's scaled reward terms, for the episode-sum bookkeeping
+    // body-terms offload (quadruped kernels, 4 waves): sub-step inputs of the lane and the helpers' (I0, p0) per joint
+    float4 fk[OFF ? 3 : 1][4][LG_BLOCK];                         // per joint: world rotation (9), angular (3) and origin (3) velocity of the body
+    float4 bt[OFF ? 3 : 1][LG_BT_QUADS][LG_BLOCK];
+    int    fk_ready;                                             // = sub-step number once the rigid-body wave has published fk[] (polled by the helpers)
 };
+typedef StepSharedT<false> StepShared;
 // episode_sums[name] += term (:203); read + zeroed for reset envs, whose sums feed extras["episode"] (reset_idx :179-183).
 // Runs on a helper wave (one lane per env): off the rigid-body wave's critical path.
 struct EpisodeSums {
@@ -685,7 +733,7 @@ struct EpisodeSums {
             sum[t] = slot >= 0 ? A.B.episode_sums[(size_t)slot * A.P.num_envs + e] : 0.0f;
         }
     }
-    LG_DEV void update(const KArgs &A, int e, int lane, const StepShared &sh) {
+    template <class SH> LG_DEV void update(const KArgs &A, int e, int lane, const SH &sh) {
         const lg_params &P = A.P;
         const bool reset = sh.rst[lane] != 0;
 #pragma unroll
@@ -709,17 +757,19 @@ struct EpisodeSums {
 
 template <class T, bool NET, bool HF, int NW> struct HelperWave {
     // wave = 1 .. LG_STEP_WAVES-1; with the actuator net also the LSTM of joint (wave - 1); all 64 lanes active
-    static LG_DEV void run(const KArgs &A, int wave, int lane, int e, int k, int d0, bool live, int64_t step,
-                           float2 (*lds_x)[LG_BLOCK], float (*lds_tau)[LG_BLOCK], StepShared &sh) {
+    static constexpr bool OFF = NW == 4 && T::L == 3;            // this wave also computes (I0, p0) of body `wave - 1` each sub-step
+    static LG_DEV void run(const KArgs &A, int wave, int lane, int e, int k, int d0, bool live, int64_t step, const float *tab,
+                           float2 (*lds_x)[LG_BLOCK], float (*lds_tau)[LG_BLOCK], StepSharedT<OFF> &sh) {
         const lg_buffers &B = A.B;
         const lg_params &P = A.P;
         const int j = wave - 1;
         LstmSplit st;
         float (*part[4])[4] = {st.h0, st.c0, st.h1, st.c1};
         float *row[4] = {nullptr, nullptr, nullptr, nullptr};
+        LstmLane LW;
         if (NET) {
             const size_t plane = (size_t)P.num_envs * (T::K * T::L);
-            const LstmLane LW = lstm_load(A.weights, lane);
+            LW = lstm_load(A.weights, lane);
             row[0] = B.sea_hidden_state + (size_t)(d0 + j) * 8; row[1] = B.sea_cell_state + (size_t)(d0 + j) * 8;     // h0, c0, h1, c1 (anymal.py:65-69)
             row[2] = B.sea_hidden_state + (plane + d0 + j) * 8; row[3] = B.sea_cell_state + (plane + d0 + j) * 8;
 #pragma unroll
@@ -728,11 +778,31 @@ template <class T, bool NET, bool HF, int NW> struct HelperWave {
                 float u[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
                 lstm_split(u, part[a][0], part[a][1]);
             }
+        }
+        if (NET || OFF) {
             for (int it = 0; it < P.decimation; it++) {
-                __syncthreads();                                   // this sub-step's (pos_err, vel) are in lds_x
-                const float2 x = lds_x[j][lane];
-                lds_tau[j][lane] = actuator_step_mfma(LW, x.x, x.y, st);
-                __syncthreads();                                   // torques published
+                __syncthreads();                                   // this sub-step has started: actuator inputs are in lds_x
+                float tau_j = 0.0f;
+                if (NET) {
+                    const float2 x = lds_x[j][lane];
+                    tau_j = actuator_step_mfma(LW, x.x, x.y, st);
+                    lds_tau[j][lane] = tau_j;
+                }
+                if (OFF) {                                         // body j's frame arrives from the rigid-body wave (long before, normally)
+                    volatile int *flag = &sh.fk_ready;
+                    while (*flag < it + 1) {}
+                    const float4 f0 = sh.fk[j][0][lane], f1 = sh.fk[j][1][lane], f2 = sh.fk[j][2][lane], f3 = sh.fk[j][3][lane];
+                    M3 R; R.m[0] = f0.x; R.m[1] = f0.y; R.m[2] = f0.z; R.m[3] = f0.w; R.m[4] = f1.x; R.m[5] = f1.y; R.m[6] = f1.z; R.m[7] = f1.w; R.m[8] = f2.x;
+                    const float *tj = tab + j * LG_JS;
+                    float Il[6];
+#pragma unroll
+                    for (int i = 0; i < 6; i++) Il[i] = tj[J_INERTIA + i];
+                    AI I0; S6 p0;
+                    body_terms(v3(P.gravity[0], P.gravity[1], P.gravity[2]), tj[J_MASS], v3(tj[J_COM], tj[J_COM + 1], tj[J_COM + 2]), Il, R,
+                               v3(f2.y, f2.z, f2.w), v3(f3.x, f3.y, f3.z), I0, p0);
+                    bt_store(sh.bt[j], lane, I0, p0);
+                }
+                __syncthreads();                                   // torques / body terms published
             }
         }
         __syncthreads();                                           // P1: final poses published
@@ -781,11 +851,13 @@ __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
     __shared__ float lds_tab[T::K * Tab<T>::STRIDE];
     __shared__ float2 lds_x[NET ? L : 1][LG_BLOCK];             // actuator inputs (pos_err, vel) of the sub-step, [joint][lane]
     __shared__ float lds_tau[NET ? L : 1][LG_BLOCK];            // actuator torques of the sub-step
-    __shared__ StepShared sh;
+    constexpr bool OFF = NW == 4 && T::L == 3;
+    __shared__ StepSharedT<OFF> sh;
     __shared__ int s_last;
     __shared__ float4 pol_xa[POL ? 4 : 1][64], pol_xb[POL ? 8 : 1][64], pol_xy[1][64];
     __shared__ float lds_act[POL ? 16 : 1][16];                 // sampled actions [action][env in block]
     LG_PROF_BEGIN();
+    if (threadIdx.x == 0) sh.fk_ready = 0;                      // published before the first use by stage_limb_table's barrier
     stage_limb_table<T>(A, lds_tab);
 
     const int N = P.num_envs;
@@ -804,7 +876,7 @@ __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
         __syncthreads();
     }
     if (wave > 0) {
-        HelperWave<T, NET, HF, NW>::run(A, wave, lane, e, k, d0, live, step, lds_x, lds_tau, sh);
+        HelperWave<T, NET, HF, NW>::run(A, wave, lane, e, k, d0, live, step, tab, lds_x, lds_tau, sh);
     } else {
     // ---- load persistent state (read once per env-step)
     float root[13], q[L], qd[L], act[L], tau[L];
@@ -840,18 +912,22 @@ __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
     LG_PROF(PF_PROLOGUE);
 #pragma unroll 1
     for (int it = 0; it < P.decimation; it++) {
-        if (NET) {
+        if (!NET) pd_torques<L>(P, tab, act, q, qd, last_qd, tau);
+        if (NET || OFF) {
+            if (NET) {
 #pragma unroll
-            for (int j = 0; j < L; j++) lds_x[j][lane] = make_float2(act[j] * P.action_scale + tab[j * LG_JS + J_Q0] - q[j], qd[j]);   // anymal.py:73-75
-            __syncthreads();                                   // actuator waves start on this sub-step
+                for (int j = 0; j < L; j++) lds_x[j][lane] = make_float2(act[j] * P.action_scale + tab[j * LG_JS + J_Q0] - q[j], qd[j]);   // anymal.py:73-75
+            }
+            __syncthreads();                                   // helper waves start on this sub-step
             auto join = [&]() {
-                __syncthreads();                               // torques published
+                __syncthreads();                               // torques / body terms published
+                if (NET) {
 #pragma unroll
-                for (int j = 0; j < L; j++) tau[j] = lds_tau[j][lane];
+                    for (int j = 0; j < L; j++) tau[j] = lds_tau[j][lane];
+                }
             };
-            physics_substep<T, HF>(A, tab, k, root, q, qd, tau, base_mass, mu, Frep, Fbase, join);
+            physics_substep<T, HF, decltype(join), OFF>(A, tab, k, root, q, qd, tau, base_mass, mu, Frep, Fbase, join, sh.bt, sh.fk, &sh.fk_ready, it + 1);
         } else {
-            pd_torques<L>(P, tab, act, q, qd, last_qd, tau);
             physics_substep<T, HF>(A, tab, k, root, q, qd, tau, base_mass, mu, Frep, Fbase);
         }
     }
