@@ -20,6 +20,10 @@ class OnPolicyRunner:
         if self.cfg.get("policy_class_name", "ActorCritic") != "ActorCritic":
             raise NotImplementedError("only the feed-forward ActorCritic is bundled")
         actor_critic = ActorCritic(env.num_obs, num_critic_obs, env.num_actions, **self.policy_cfg).to(device)
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            for prm in actor_critic.parameters():       # replicas start from rank 0's weights (env seeds differ per rank)
+                dist.broadcast(prm.data, src=0)
         self.alg = PPO(actor_critic, device=device, **self.alg_cfg)
         self.num_steps_per_env = self.cfg["num_steps_per_env"]
         self.save_interval = self.cfg["save_interval"]

@@ -150,6 +150,21 @@ def test_fused_policy_step_equals_actor_kernel_plus_step():
         env2.step_policy(actor)
 
 
+def test_two_rank_training_on_one_gpu(tmp_path):
+    """scripts/train.py under torch.distributed.run: 2 ranks (sharing cuda:0 here, gloo instead of RCCL) shard the envs, rank 0's
+    weights are broadcast, the PPO collectives keep the replicas in step, rank 0 alone logs.  Rehearsal of the 8-GPU launch."""
+    import os, socket, subprocess, sys
+    sck = socket.socket(); sck.bind(("127.0.0.1", 0)); port = sck.getsockname()[1]; sck.close()
+    repo = os.path.dirname(os.path.dirname(os.path.realpath(__file__)))
+    env = dict(os.environ, LG_LOCAL_DEVICE="0", LG_DIST_BACKEND="gloo", PYTHONPATH=repo, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           "-m", "legged_games_gym_amd.scripts.train", "--task=anymal_c_flat", "--headless", "--num_envs", "256", "--max_iterations", "3"]
+    r = subprocess.run(cmd, cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("it ")]
+    assert len(lines) == 3 and "it 2/3" in lines[-1]                 # one logger (rank 0), all iterations done
+
+
 def test_step_returns_a_fresh_observation_tensor_like_the_reference():
     """legged_robot.py:215 re-creates obs_buf each step; rsl_rl's PPO.act holds the previous tensor by reference until
     process_env_step.  The obs returned by step t must therefore survive step t+1 untouched."""
