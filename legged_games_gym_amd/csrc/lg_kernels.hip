@@ -710,18 +710,18 @@ LG_DEV void finish_extras(const KArgs &A, int t, int64_t step_used, bool publish
 // of every lane (state resident in their registers for the whole step) and compute each sub-step's torques while wave 0
 // does the torque-independent kinematics half.  Hand-over through LDS (lds_x -> lds_tau), two barriers per sub-step.
 // Post-physics, every variant: the helper waves join the height sampling / height observations (HeightCrew), 4 x the lanes.
-template <bool OFF> struct StepSharedT {                         // LDS hand-over between the rigid-body wave and the helpers
+template <bool OFF, int L = 3> struct StepSharedT {              // LDS hand-over between the rigid-body wave and the helpers
     float pose[LG_BLOCK][5];                                     // x, y, z, q.z, q.w of the lane's env after the last sub-step
     float hsum[LG_STEP_WAVES][LG_BLOCK];                         // partial sums of (root z - height) per wave
     float root_z[LG_BLOCK];                                      // root z after the reset decision (observation input, Q7)
     int   rst[LG_BLOCK];                                         // reset flag of the lane's env
     float r_t[LG_NUM_REWARD_TERMS][LG_BLOCK];                    // this step's scaled reward terms, for the episode-sum bookkeeping
     // body-terms offload (quadruped kernels, 4 waves): sub-step inputs of the lane and the helpers' (I0, p0) per joint
-    float4 fk[OFF ? 3 : 1][4][LG_BLOCK];                         // per joint: world rotation (9), angular (3) and origin (3) velocity of the body
-    float4 bt[OFF ? 3 : 1][LG_BT_QUADS][LG_BLOCK];
+    float4 fk[OFF ? L : 1][4][LG_BLOCK];                         // per joint: world rotation (9), angular (3) and origin (3) velocity of the body
+    float4 bt[OFF ? L : 1][LG_BT_QUADS][LG_BLOCK];
     int    fk_ready;                                             // = sub-step number once the rigid-body wave has published fk[] (polled by the helpers)
 };
-typedef StepSharedT<false> StepShared;
+
 // episode_sums[name] += term (:203); read + zeroed for reset envs, whose sums feed extras["episode"] (reset_idx :179-183).
 // Runs on a helper wave (one lane per env): off the rigid-body wave's critical path.
 struct EpisodeSums {
@@ -757,9 +757,10 @@ struct EpisodeSums {
 
 template <class T, bool NET, bool HF, int NW> struct HelperWave {
     // wave = 1 .. LG_STEP_WAVES-1; with the actuator net also the LSTM of joint (wave - 1); all 64 lanes active
-    static constexpr bool OFF = NW == 4 && T::L == 3;            // this wave also computes (I0, p0) of body `wave - 1` each sub-step
+    static constexpr bool OFF = NW >= 2;                         // the helpers also compute (I0, p0) of the limb bodies each sub-step:
+                                                                 // wave w takes bodies w-1, w-1 + (NW-1), ...
     static LG_DEV void run(const KArgs &A, int wave, int lane, int e, int k, int d0, bool live, int64_t step, const float *tab,
-                           float2 (*lds_x)[LG_BLOCK], float (*lds_tau)[LG_BLOCK], StepSharedT<OFF> &sh) {
+                           float2 (*lds_x)[LG_BLOCK], float (*lds_tau)[LG_BLOCK], StepSharedT<OFF, T::L> &sh) {
         const lg_buffers &B = A.B;
         const lg_params &P = A.P;
         const int j = wave - 1;
@@ -788,19 +789,22 @@ template <class T, bool NET, bool HF, int NW> struct HelperWave {
                     tau_j = actuator_step_mfma(LW, x.x, x.y, st);
                     lds_tau[j][lane] = tau_j;
                 }
-                if (OFF) {                                         // body j's frame arrives from the rigid-body wave (long before, normally)
+                if (OFF) {                                         // the bodies' frames arrive from the rigid-body wave (long before, normally)
                     volatile int *flag = &sh.fk_ready;
                     while (*flag < it + 1) {}
-                    const float4 f0 = sh.fk[j][0][lane], f1 = sh.fk[j][1][lane], f2 = sh.fk[j][2][lane], f3 = sh.fk[j][3][lane];
-                    M3 R; R.m[0] = f0.x; R.m[1] = f0.y; R.m[2] = f0.z; R.m[3] = f0.w; R.m[4] = f1.x; R.m[5] = f1.y; R.m[6] = f1.z; R.m[7] = f1.w; R.m[8] = f2.x;
-                    const float *tj = tab + j * LG_JS;
-                    float Il[6];
+#pragma unroll 1
+                    for (int b = j; b < T::L; b += NW - 1) {
+                        const float4 f0 = sh.fk[b][0][lane], f1 = sh.fk[b][1][lane], f2 = sh.fk[b][2][lane], f3 = sh.fk[b][3][lane];
+                        M3 R; R.m[0] = f0.x; R.m[1] = f0.y; R.m[2] = f0.z; R.m[3] = f0.w; R.m[4] = f1.x; R.m[5] = f1.y; R.m[6] = f1.z; R.m[7] = f1.w; R.m[8] = f2.x;
+                        const float *tb = tab + b * LG_JS;
+                        float Il[6];
 #pragma unroll
-                    for (int i = 0; i < 6; i++) Il[i] = tj[J_INERTIA + i];
-                    AI I0; S6 p0;
-                    body_terms(v3(P.gravity[0], P.gravity[1], P.gravity[2]), tj[J_MASS], v3(tj[J_COM], tj[J_COM + 1], tj[J_COM + 2]), Il, R,
-                               v3(f2.y, f2.z, f2.w), v3(f3.x, f3.y, f3.z), I0, p0);
-                    bt_store(sh.bt[j], lane, I0, p0);
+                        for (int i = 0; i < 6; i++) Il[i] = tb[J_INERTIA + i];
+                        AI I0; S6 p0;
+                        body_terms(v3(P.gravity[0], P.gravity[1], P.gravity[2]), tb[J_MASS], v3(tb[J_COM], tb[J_COM + 1], tb[J_COM + 2]), Il, R,
+                                   v3(f2.y, f2.z, f2.w), v3(f3.x, f3.y, f3.z), I0, p0);
+                        bt_store(sh.bt[b], lane, I0, p0);
+                    }
                 }
                 __syncthreads();                                   // torques / body terms published
             }
@@ -851,8 +855,8 @@ __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
     __shared__ float lds_tab[T::K * Tab<T>::STRIDE];
     __shared__ float2 lds_x[NET ? L : 1][LG_BLOCK];             // actuator inputs (pos_err, vel) of the sub-step, [joint][lane]
     __shared__ float lds_tau[NET ? L : 1][LG_BLOCK];            // actuator torques of the sub-step
-    constexpr bool OFF = NW == 4 && T::L == 3;
-    __shared__ StepSharedT<OFF> sh;
+    constexpr bool OFF = NW >= 2;
+    __shared__ StepSharedT<OFF, L> sh;
     __shared__ int s_last;
     __shared__ float4 pol_xa[POL ? 4 : 1][64], pol_xb[POL ? 8 : 1][64], pol_xy[1][64];
     __shared__ float lds_act[POL ? 16 : 1][16];                 // sampled actions [action][env in block]
