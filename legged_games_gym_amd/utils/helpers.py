@@ -6,7 +6,8 @@ Mirrors the in-scope part of reference ``legged_gym/utils/helpers.py``:
 ``parse_sim_params`` (:79-101), ``get_load_path`` (:103-125),
 ``update_cfg_from_args`` (:159-182) and ``get_args`` (:184-210).  The Isaac Gym
 ``gymutil.parse_arguments`` call is replaced by ``argparse`` exposing the same
-flag names; JIT policy export and the game-layer loaders are out of scope.
+flag names; ``export_policy_as_jit`` (:212-222, feed-forward actors); the recurrent exporter and the game-layer
+loaders are out of scope.
 """
 import argparse
 import os
@@ -133,6 +134,19 @@ def update_cfg_from_args(env_cfg, cfg_train, args):
             if val is not None:
                 setattr(cfg_train.runner, name, val)
     return env_cfg, cfg_train
+
+
+def export_policy_as_jit(actor_critic, path):
+    """TorchScript copy of the actor for deployment: ``<path>/policy_1.pt`` (reference helpers.py:212-222; the reference's
+    LSTM exporter for recurrent policies is not needed by any in-scope task)."""
+    import copy
+    if hasattr(actor_critic, "memory_a"):
+        raise NotImplementedError("recurrent policy export is out of scope")
+    os.makedirs(path, exist_ok=True)
+    target = os.path.join(path, "policy_1.pt")
+    actor = copy.deepcopy(actor_critic.actor).to("cpu").eval()
+    torch.jit.script(actor).save(target)
+    return target
 
 
 def get_args(argv=None):

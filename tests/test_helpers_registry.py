@@ -68,3 +68,16 @@ def test_reward_scale_without_function_raises_like_the_reference():
     cfg.rewards.scales.feet_stumble = -1.0                    # quirk Q3: no _reward_feet_stumble
     with pytest.raises(AttributeError, match="_reward_feet_stumble"):
         packing.build_params(cfg, load_model(cfg.asset.file), 0.005, 8, 1)
+
+
+def test_export_policy_as_jit_round_trip(tmp_path):
+    import torch
+    from legged_games_gym_amd.rl import ActorCritic
+    from legged_games_gym_amd.utils.helpers import export_policy_as_jit
+    torch.manual_seed(0)
+    ac = ActorCritic(48, 48, 12, actor_hidden_dims=[32, 16], critic_hidden_dims=[32, 16], activation="elu")
+    target = export_policy_as_jit(ac, str(tmp_path / "exported" / "policies"))
+    assert target.endswith("policy_1.pt")
+    jit = torch.jit.load(target)                    # a file this test just wrote
+    x = torch.randn(5, 48)
+    assert torch.allclose(jit(x), ac.act_inference(x), atol=1e-6)
