@@ -81,3 +81,22 @@ def test_export_policy_as_jit_round_trip(tmp_path):
     jit = torch.jit.load(target)                    # a file this test just wrote
     x = torch.randn(5, 48)
     assert torch.allclose(jit(x), ac.act_inference(x), atol=1e-6)
+
+
+def test_logger_surface_and_headless_plot(tmp_path, capsys):
+    import numpy as np
+    import torch
+    from legged_games_gym_amd.utils.logger import Logger
+    lg = Logger(0.02, out_dir=str(tmp_path))
+    for i in range(20):
+        lg.log_states({"dof_pos": 0.1 * i, "dof_pos_target": 0.1 * i + 0.01, "dof_vel": 1.0, "dof_torque": 2.0, "base_vel_x": 0.5, "command_x": 0.5,
+                       "contact_forces_z": np.array([1.0, 2.0, 3.0, 4.0])})
+    lg.log_rewards({"rew_tracking_lin_vel": torch.tensor(0.5), "terrain_level": torch.tensor(3.0)}, 4)
+    lg.log_rewards({"rew_tracking_lin_vel": torch.tensor(1.0)}, 4)
+    lg.print_rewards()
+    out = capsys.readouterr().out
+    assert "rew_tracking_lin_vel: 0.75" in out and "terrain_level" not in out and "Total number of episodes: 8" in out
+    path = lg.plot_states()
+    assert os.path.isfile(path) and os.path.getsize(path) > 100
+    lg.reset()
+    assert not lg.state_log and not lg.rew_log
