@@ -345,6 +345,10 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, int lane_k, float 
 
     LG_PROF(PF_KINEMATICS);
     torques_ready();
+    if (OFFLOAD) {
+#pragma unroll
+        for (int j = 0; j < L; j++) bt_load(bt[j], threadIdx.x % LG_BLOCK, I0[j], p0[j]);
+    }
     LG_PROF(PF_TORQUE);
     // ---- articulated-body passes with the contact impedances folded in
     S6 U[L], acc0;
@@ -357,9 +361,7 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, int lane_k, float 
 #pragma unroll
         for (int j = L - 1; j >= 0; j--) {
             const float *tj = tab + j * LG_JS;
-            AI IA; S6 pA;
-            if (OFFLOAD) bt_load(bt[j], threadIdx.x % LG_BLOCK, IA, pA);     // re-read per pass: 7 LDS loads instead of 27 live registers
-            else { IA = I0[j]; pA = p0[j]; }
+            AI IA = I0[j]; S6 pA = p0[j];
 #pragma unroll
             for (int i = 0; i < NPT; i++) if (T::pt_joint(i) == j) contact_assemble(cl[i], P, kn, IA, pA);
             if (j < L - 1) { ai_add(IA, Ia); pA = pA + pa; }
