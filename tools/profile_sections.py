@@ -16,7 +16,7 @@ NAMES = ["prologue (tables, state loads)", "torques (actuator LSTM / PD)", "kine
 
 if sys.argv[1:2] == ["build"]:
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-fno-slp-vectorize",
-           "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-mllvm", "-amdgpu-mfma-vgpr-form", "-DLG_PROFILE", "-o", LIB, os.path.join(CSRC, "lg_kernels.hip")]
+           "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-mllvm", "-amdgpu-mfma-vgpr-form", "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0", "-DLG_PROFILE", "-o", LIB, os.path.join(CSRC, "lg_kernels.hip")]
     print(" ".join(cmd)); subprocess.run(cmd, check=True); sys.exit(0)
 
 os.environ["LG_HIP_LIB"] = LIB
