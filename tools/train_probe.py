@@ -13,6 +13,16 @@ if os.environ.get("LG_SEED"):            # the env seeds from the registered tra
     train_cfg0.seed = int(os.environ["LG_SEED"])
 if os.environ.get("LG_ENTROPY"):
     train_cfg0.algorithm.entropy_coef = float(os.environ["LG_ENTROPY"])
+if os.environ.get("LG_PLANE"):
+    env_cfg.terrain.mesh_type = "plane"; env_cfg.terrain.curriculum = False; env_cfg.terrain.measure_heights = bool(int(os.environ.get("LG_HEIGHTS", "1")))
+if os.environ.get("LG_NO_PUSH"):
+    env_cfg.domain_rand.push_robots = False
+if os.environ.get("LG_NO_NOISE"):
+    env_cfg.noise.add_noise = False
+if os.environ.get("LG_NO_CURRICULUM"):
+    env_cfg.terrain.curriculum = False
+if os.environ.get("LG_KD"):
+    env_cfg.control.damping = {k: float(os.environ["LG_KD"]) for k in env_cfg.control.damping}
 if os.environ.get("LG_UNCLIPPED"):
     env_cfg.rewards.only_positive_rewards = False
 if os.environ.get("LG_INIT_STD"):
