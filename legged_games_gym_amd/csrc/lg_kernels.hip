@@ -6,9 +6,10 @@
 //   implicit contacts] -> post_physics_step (base-frame quantities, command resampling,
 //   height sampling, pushes, termination, the _reward_* sum, predicated reset_idx,
 //   compute_observations with noise, last_* bookkeeping) -> clip observations.
-// Persistent state is read once and written once per env-step.
+// Persistent state is read once and written once per env-step.  A workgroup is 64 (env, limb) lanes x up to four waves:
+// the rigid-body wave plus helper waves (actuator LSTMs, body inertia terms, height sampling, bookkeeping) -- see k_step.
 //
-// Build: hipcc --offload-arch=gfx950 -O3 -shared -fPIC lg_kernels.hip -o liblegged_hip.so
+// Build: __graft_entry__.build() (hipcc --offload-arch=gfx950 -O3 -shared -fPIC + the flags explained in DESIGN.md section 5)
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
@@ -20,7 +21,7 @@
 
 using namespace lg;
 
-#define LG_BLOCK 64            // one wave per workgroup: 4096 envs x 4 limbs = 256 waves = one per CU
+#define LG_BLOCK 64            // (env, limb) lanes per workgroup = one wave; 4096 envs x 4 limbs = 256 workgroups = one per CU
 #define LG_JS 40               // floats per joint in the LDS limb table
 #define LG_PASSES 2
 
