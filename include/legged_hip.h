@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LG_ABI_VERSION        10
+#define LG_ABI_VERSION        11
 
 #define LG_MAX_LIMBS          4
 #define LG_MAX_CHAIN          6
@@ -219,6 +219,20 @@ int  lg_step_policy(lg_sim *sim, lg_policy *p, const float *obs, float *actions,
  * values (un-normalised: the caller normalises over the global batch).  Device pointers, asynchronous on `stream`. */
 int  lg_gae_returns(const float *rewards, const float *values, const uint8_t *dones, const float *last_values, float gamma, float lam,
                     float *returns, float *advantages, int32_t num_steps, int32_t num_envs, void *stream);
+
+/* Fused PPO loss and its gradient w.r.t. the network outputs for one mini-batch (rsl_rl PPO.update's surrogate / clipped value /
+ * entropy terms and the adaptive-KL statistic, [EXTERNAL]; hyper-parameters legged_robot_config.py:215-228):
+ *   loss = mean(max(-A r, -A clamp(r, 1-c, 1+c))) + value_coef mean(max((v-R)^2, (v_clip-R)^2)) - entropy_coef mean(H),
+ *   r = exp(log pi(a) - old_log_prob), pi = N(mu, std), v_clip = v_old + clamp(v - v_old, -c, c).
+ * mu [mb, A] / value [mb] are the actor / critic outputs of mini-batch row i; `rows[i]` is its row in the rollout storage, from
+ * which actions, old_log_prob, old_mu, old_sigma [B, A] and advantages, old_values, returns [B] are gathered.  Outputs:
+ * d_mu [mb, A], d_value [mb], d_std [A] = d loss / d(.)  and  stats[4] = {surrogate mean, value-loss mean, KL mean, entropy}.
+ * Device pointers; asynchronous on `stream` (capturable).  use_clipped_value != 0 selects the clipped value loss. */
+int  lg_ppo_loss(const float *mu, const float *std, const float *value, const int64_t *rows, const float *actions,
+                 const float *old_log_prob, const float *old_mu, const float *old_sigma, const float *advantages,
+                 const float *old_values, const float *returns, float clip, float value_coef, float entropy_coef,
+                 int32_t use_clipped_value, float *d_mu, float *d_std, float *d_value, float *stats, int32_t mb, int32_t num_actions,
+                 void *stream);
 
 const char *lg_last_error(void);
 int  lg_abi_version(void);

@@ -1534,6 +1534,104 @@ int lg_gae_returns(const float *rewards, const float *values, const uint8_t *don
     return 0;
 }
 
+// ------------------------------------------------------------------ fused PPO loss + gradient w.r.t. the network outputs
+#define LG_PPO_MAX_ACTIONS 16
+__global__ void __launch_bounds__(256) k_ppo_loss(const float *__restrict__ mu, const float *__restrict__ stdp, const float *__restrict__ value,
+                                                  const int64_t *__restrict__ rows, const float *__restrict__ actions, const float *__restrict__ old_lp,
+                                                  const float *__restrict__ old_mu, const float *__restrict__ old_sigma, const float *__restrict__ adv,
+                                                  const float *__restrict__ old_values, const float *__restrict__ returns, float clip, float vcoef,
+                                                  float ecoef, int clipped_value, float *__restrict__ d_mu, float *__restrict__ d_std,
+                                                  float *__restrict__ d_value, float *__restrict__ stats, int mb, int A) {
+    __shared__ float red[4 + LG_PPO_MAX_ACTIONS];
+    if (threadIdx.x < 4 + LG_PPO_MAX_ACTIONS) red[threadIdx.x] = 0.0f;
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const float inv_n = 1.0f / (float)mb;
+    float acc[4] = {0, 0, 0, 0}, gstd[LG_PPO_MAX_ACTIONS];
+#pragma unroll
+    for (int a = 0; a < LG_PPO_MAX_ACTIONS; a++) gstd[a] = 0.0f;
+    if (i < mb) {
+        const size_t r = (size_t)rows[i];
+        float lp = 0.0f, kl = 0.0f, z[LG_PPO_MAX_ACTIONS], isg[LG_PPO_MAX_ACTIONS];
+#pragma unroll
+        for (int a = 0; a < LG_PPO_MAX_ACTIONS; a++) if (a < A) {
+            const float sg = stdp[a], m = mu[(size_t)i * A + a], om = old_mu[r * A + a], os = old_sigma[r * A + a];
+            isg[a] = 1.0f / sg;
+            z[a] = (actions[r * A + a] - m) * isg[a];
+            lp += -0.5f * z[a] * z[a] - __logf(sg) - 0.918938533f;                     // log N(a; mu, sigma)
+            kl += __logf(sg / os + 1.0e-5f) + (os * os + (om - m) * (om - m)) * (0.5f * isg[a] * isg[a]) - 0.5f;
+        }
+        const float ad = adv[r], ratio = __expf(lp - old_lp[r]);
+        const float s1 = -ad * ratio, s2 = -ad * fminf(fmaxf(ratio, 1.0f - clip), 1.0f + clip);
+        const bool inside = ratio >= 1.0f - clip && ratio <= 1.0f + clip;
+        // d max(s1, s2) / d lp: s1 wins (or ties, inside the clamp range) -> -A r; the clamped branch has no gradient outside the range
+        const float dlp = (s1 > s2 || inside) ? -ad * ratio : (s1 == s2 ? -0.5f * ad * ratio : 0.0f);
+        acc[0] = fmaxf(s1, s2);
+        const float v = value[i], tv = old_values[r], R = returns[r];
+        float dv;
+        if (clipped_value) {
+            const float dvt = v - tv, vc = tv + fminf(fmaxf(dvt, -clip), clip);
+            const float v1 = (v - R) * (v - R), v2 = (vc - R) * (vc - R);
+            const bool in_v = dvt >= -clip && dvt <= clip;
+            acc[1] = fmaxf(v1, v2);
+            dv = (v1 > v2 || in_v) ? 2.0f * (v - R) : (v1 == v2 ? (v - R) : 0.0f);
+        } else {
+            acc[1] = (R - v) * (R - v);
+            dv = 2.0f * (v - R);
+        }
+        acc[2] = kl;
+        d_value[i] = vcoef * inv_n * dv;
+#pragma unroll
+        for (int a = 0; a < LG_PPO_MAX_ACTIONS; a++) if (a < A) {
+            d_mu[(size_t)i * A + a] = inv_n * dlp * z[a] * isg[a];                      // d lp / d mu = (a - mu) / sigma^2
+            gstd[a] = inv_n * dlp * (z[a] * z[a] - 1.0f) * isg[a];                      // d lp / d sigma = ((a - mu)^2 / sigma^2 - 1) / sigma
+        }
+    }
+    // block reduction of the three means and of d loss / d sigma, then one atomic per value
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int q = 0; q < 3; q++) acc[q] += __shfl_xor(acc[q], o);
+#pragma unroll
+        for (int a = 0; a < LG_PPO_MAX_ACTIONS; a++) gstd[a] += __shfl_xor(gstd[a], o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int q = 0; q < 3; q++) atomicAdd(&red[q], acc[q]);
+#pragma unroll
+        for (int a = 0; a < LG_PPO_MAX_ACTIONS; a++) if (a < A) atomicAdd(&red[4 + a], gstd[a]);
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) atomicAdd(stats + threadIdx.x, red[threadIdx.x] * inv_n);
+    if (threadIdx.x >= 4 && threadIdx.x < 4 + A) atomicAdd(d_std + (threadIdx.x - 4), red[threadIdx.x]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {                                          // entropy is row-independent: sum_a (0.5 + 0.5 log 2 pi + log sigma_a)
+        float H = 0.0f;
+        for (int a = 0; a < A; a++) { H += 1.418938533f + __logf(stdp[a]); atomicAdd(d_std + a, -ecoef / stdp[a]); }
+        stats[3] = H;
+    }
+}
+
+__global__ void k_zero2(float *a, int na, float *b, int nb) {
+    if ((int)threadIdx.x < na) a[threadIdx.x] = 0.0f;
+    if ((int)threadIdx.x < nb) b[threadIdx.x] = 0.0f;
+}
+
+int lg_ppo_loss(const float *mu, const float *std, const float *value, const int64_t *rows, const float *actions, const float *old_log_prob,
+                const float *old_mu, const float *old_sigma, const float *advantages, const float *old_values, const float *returns, float clip,
+                float value_coef, float entropy_coef, int32_t use_clipped_value, float *d_mu, float *d_std, float *d_value, float *stats,
+                int32_t mb, int32_t num_actions, void *stream) {
+    if (!mu || !std || !value || !rows || !actions || !old_log_prob || !old_mu || !old_sigma || !advantages || !old_values || !returns || !d_mu ||
+        !d_std || !d_value || !stats) return fail(-1, "null argument");
+    if (num_actions < 1 || num_actions > LG_PPO_MAX_ACTIONS) return fail(-4, "lg_ppo_loss supports 1..16 actions");
+    if (mb <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_zero2, dim3(1), dim3(64), 0, st, stats, 4, d_std, (int)num_actions);     // (a kernel, not hipMemsetAsync: replayed inside HIP graphs)
+    hipLaunchKernelGGL(k_ppo_loss, dim3((mb + 255) / 256), dim3(256), 0, st, mu, std, value, rows, actions, old_log_prob, old_mu, old_sigma, advantages,
+                       old_values, returns, clip, value_coef, entropy_coef, (int)use_clipped_value, d_mu, d_std, d_value, stats, (int)mb, (int)num_actions);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 const char *lg_last_error(void) { return g_err; }
 int lg_abi_version(void) { return LG_ABI_VERSION; }
 #ifdef LG_PROFILE

@@ -125,13 +125,18 @@ class RolloutStorage:
 class PPO:
     def __init__(self, actor_critic, num_learning_epochs=1, num_mini_batches=1, clip_param=0.2, gamma=0.998, lam=0.95,
                  value_loss_coef=1.0, entropy_coef=0.0, learning_rate=1e-3, max_grad_norm=1.0,
-                 use_clipped_value_loss=True, schedule="fixed", desired_kl=0.01, device="cpu", graphed_update=True):
+                 use_clipped_value_loss=True, schedule="fixed", desired_kl=0.01, device="cpu", graphed_update=True, fused_loss=True):
         self.device = device
         # Single-GPU runs replay one captured HIP graph per mini-batch step (forward, losses, backward, grad clip, Adam and
         # the adaptive-KL learning rate all on the device): the flat networks' update is launch-bound (~150 tiny kernels).
         self._graph_ok = bool(graphed_update) and str(device).startswith("cuda")
         self._graph, self._graph_key = None, None
         self._updates_done = 0
+        # ... and the surrogate / value / entropy losses with their gradients w.r.t. the network outputs come from ONE HIP kernel
+        # (``lg_ppo_loss``) instead of ~100 small torch kernels; autograd only runs through the two MLPs.
+        import os as _os
+        self._fused_loss = bool(fused_loss) and self._graph_ok and _os.environ.get("LG_PPO_FUSED_LOSS", "1") != "0"
+        self._lib = None
         self.desired_kl, self.schedule, self.learning_rate = desired_kl, schedule, learning_rate
         self.actor_critic = actor_critic.to(device)
         self.storage = None
@@ -214,8 +219,54 @@ class PPO:
         return (obs, cobs, st.actions.flatten(0, 1), st.values.flatten(0, 1), st.advantages.flatten(0, 1), st.returns.flatten(0, 1),
                 st.actions_log_prob.flatten(0, 1), st.mu.flatten(0, 1), st.sigma.flatten(0, 1))
 
+    def _fused_ready(self):
+        if not self._fused_loss:
+            return False
+        if self._lib is None:
+            try:
+                from .. import capi
+                self._lib = capi.load_library()
+            except Exception:
+                self._lib = False
+        ac = self.actor_critic
+        return bool(self._lib) and hasattr(ac, "actor") and hasattr(ac, "critic") and hasattr(ac, "std") and ac.std.numel() <= 16
+
+    def _mb_step_fused(self):
+        """Mini-batch step with the fused loss kernel: MLP forward (torch) -> lg_ppo_loss -> MLP backward (autograd) -> clip -> Adam."""
+        st, ac, ix = self.storage, self.actor_critic, self._ix
+        obs_all = st.observations.flatten(0, 1)
+        obs = obs_all[ix]
+        cobs = st.privileged_observations.flatten(0, 1)[ix] if st.privileged_observations is not None else obs
+        mu = ac.actor(obs)
+        val = ac.critic(cobs)
+        mb, A = mu.shape
+        if getattr(self, "_d_mu", None) is None or self._d_mu.shape != mu.shape:
+            self._d_mu, self._d_val = torch.empty_like(mu), torch.empty(mb, 1, device=mu.device)
+            self._d_std, self._stats = torch.zeros(A, device=mu.device), torch.zeros(4, device=mu.device)
+        p = lambda t: t.data_ptr()
+        rc = self._lib.lg_ppo_loss(p(mu), p(ac.std), p(val), p(ix), p(st.actions), p(st.actions_log_prob), p(st.mu), p(st.sigma), p(st.advantages),
+                                   p(st.values), p(st.returns), float(self.clip_param), float(self.value_loss_coef), float(self.entropy_coef),
+                                   int(bool(self.use_clipped_value_loss)), p(self._d_mu), p(self._d_std), p(self._d_val), p(self._stats), int(mb), int(A),
+                                   torch.cuda.current_stream(mu.device).cuda_stream)
+        if rc != 0:
+            raise RuntimeError(f"lg_ppo_loss failed ({rc}): {self._lib.lg_last_error().decode()}")
+        if self.desired_kl is not None and self.schedule == "adaptive":
+            with torch.no_grad():
+                kl, lr = self._stats[2], self._lr
+                down, up = torch.clamp(lr / 1.5, min=1e-5), torch.clamp(lr * 1.5, max=1e-2)
+                self._lr.copy_(torch.where(kl > self.desired_kl * 2.0, down, torch.where((kl < self.desired_kl / 2.0) & (kl > 0.0), up, lr)))
+        torch.autograd.backward([mu, val], [self._d_mu, self._d_val])
+        ac.std.grad = self._d_std
+        nn.utils.clip_grad_norm_(ac.parameters(), self.max_grad_norm)
+        self.optimizer.step()
+        with torch.no_grad():
+            self._acc[0] += self._stats[1]
+            self._acc[1] += self._stats[0]
+
     def _mb_step(self):
         """One mini-batch step on the rows listed in ``self._ix``; everything stays on the device (no host decisions)."""
+        if self._fused_ready():
+            return self._mb_step_fused()
         ix = self._ix
         obs, cobs, act, tval, adv, ret, old_lp, old_mu, old_sig = (t[ix] for t in self._flat())
         ac = self.actor_critic

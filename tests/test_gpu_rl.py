@@ -35,6 +35,47 @@ def test_gae_kernel_matches_the_torch_scan():
     assert abs(float(ret_k[t, e, 0]) - float(st.rewards[t, e, 0])) < 1e-6
 
 
+def test_fused_ppo_loss_matches_autograd():
+    """lg_ppo_loss: loss statistics and d loss / d (mu, std, value) against torch autograd on the reference's loss expression."""
+    from legged_games_gym_amd import capi
+    lib = capi.load_library()
+    torch.manual_seed(1)
+    st = _storage(T=8, N=500, seed=3)
+    st.compute_returns(torch.zeros(500, 1, device="cuda"), 0.99, 0.95)
+    B, A, mb = 8 * 500, 12, 1500
+    ix = torch.randperm(B, device="cuda")[:mb]
+    for clipped in (1, 0):
+        mu = (st.mu.flatten(0, 1)[ix] + 0.3 * torch.randn(mb, A, device="cuda")).requires_grad_()
+        std = (0.8 + 0.4 * torch.rand(A, device="cuda")).requires_grad_()
+        val = (st.values.flatten(0, 1)[ix] + 0.4 * torch.randn(mb, 1, device="cuda")).requires_grad_()
+        act, olp, omu, osg = (t.flatten(0, 1)[ix] for t in (st.actions, st.actions_log_prob, st.mu, st.sigma))
+        adv, tval, ret = (t.flatten(0, 1)[ix] for t in (st.advantages, st.values, st.returns))
+        clip, vc, ec = 0.2, 1.0, 0.01
+        dist_ = torch.distributions.Normal(mu, mu * 0.0 + std)
+        lp = dist_.log_prob(act).sum(-1)
+        ratio = torch.exp(lp - olp.squeeze())
+        a = adv.squeeze()
+        surrogate = torch.max(-a * ratio, -a * torch.clamp(ratio, 1 - clip, 1 + clip)).mean()
+        if clipped:
+            vclip = tval + (val - tval).clamp(-clip, clip)
+            vloss = torch.max((val - ret).pow(2), (vclip - ret).pow(2)).mean()
+        else:
+            vloss = (ret - val).pow(2).mean()
+        ent = dist_.entropy().sum(-1).mean()
+        kl = torch.sum(torch.log(std / osg + 1e-5) + (osg.square() + (omu - mu).square()) / (2.0 * std.square()) - 0.5, dim=-1).mean()
+        (surrogate + vc * vloss - ec * ent).backward()
+        d_mu, d_val, d_std, stats = torch.empty(mb, A, device="cuda"), torch.empty(mb, 1, device="cuda"), torch.zeros(A, device="cuda"), torch.zeros(4, device="cuda")
+        p = lambda t: t.data_ptr()
+        rc = lib.lg_ppo_loss(p(mu), p(std), p(val), p(ix), p(st.actions), p(st.actions_log_prob), p(st.mu), p(st.sigma), p(st.advantages), p(st.values),
+                             p(st.returns), clip, vc, ec, clipped, p(d_mu), p(d_std), p(d_val), p(stats), mb, A, torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        ref = torch.stack((surrogate, vloss, kl, ent)).detach()
+        assert float((stats - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max())), (stats, ref)
+        assert float((d_mu - mu.grad).abs().max()) < 1e-6 + 1e-4 * float(mu.grad.abs().max())
+        assert float((d_val - val.grad).abs().max()) < 1e-7 + 1e-4 * float(val.grad.abs().max())
+        assert float((d_std - std.grad).abs().max()) < 1e-6 + 1e-4 * float(std.grad.abs().max())
+
+
 def test_graph_captured_update_equals_the_eager_update():
     """Same data, same initial weights, same permutations: three updates with the captured mini-batch graph (first one is the
     eager warm-up) against three eager updates."""
@@ -57,6 +98,6 @@ def test_graph_captured_update_equals_the_eager_update():
     (l_e, p_e, lr_e), (l_g, p_g, lr_g) = out
     assert abs(lr_e - lr_g) < 1e-9 * max(1.0, lr_e) + 1e-12 or abs(lr_e - lr_g) / lr_e < 1e-5
     for (ve, se), (vg, sg) in zip(l_e, l_g):
-        assert abs(ve - vg) < 1e-5 and abs(se - sg) < 1e-5
+        assert abs(ve - vg) < 2e-5 and abs(se - sg) < 2e-5
     for a, b in zip(p_e, p_g):
-        assert float((a - b).abs().max()) < 2e-5
+        assert float((a - b).abs().max()) < 1e-4          # fused loss kernel vs torch loss: rounding, amplified by three Adam updates
