@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LG_ABI_VERSION        11
+#define LG_ABI_VERSION        12
 
 #define LG_MAX_LIMBS          4
 #define LG_MAX_CHAIN          6
@@ -203,6 +203,11 @@ void lg_policy_destroy(lg_policy *p);
  * (>= 0) or, when -1, (*step_counter + 1) is read on the device (graph replay).  deterministic != 0 returns the mean. */
 int  lg_policy_act(lg_policy *p, const float *obs, float *actions, float *mean, int32_t num_envs, uint64_t seed,
                    int64_t step, const int64_t *step_counter, int32_t deterministic, void *stream);
+
+/* Refresh an existing policy from DEVICE tensors (torch Linear layout [out, in], biases [out], std [num_actions]) without a host
+ * round trip: one pack kernel per layer on `stream`.  Same dims as at lg_policy_create.  For training loops that re-use
+ * the MFMA actor for every rollout (rl/runner.py). */
+int  lg_policy_load_device(lg_policy *p, const float *const weights[4], const float *const biases[4], const float *std, void *stream);
 
 /* Fused rollout step: actions = actor(obs) + std * eps (as lg_policy_act, same noise stream keyed by the step counter)
  * immediately followed by lg_step on those actions, in ONE launch.  `obs` is the observation tensor of the previous step

@@ -16,7 +16,7 @@ from typing import Dict, Optional
 
 import numpy as np
 
-LG_ABI_VERSION = 11
+LG_ABI_VERSION = 12
 LG_MAX_LIMBS, LG_MAX_CHAIN, LG_MAX_DOF = 4, 6, 12
 LG_MAX_LIMB_POINTS, LG_MAX_BASE_POINTS, LG_MAX_BODIES = 8, 4, 20
 LG_MAX_HEIGHT_POINTS, LG_ACTUATOR_FLOATS = 192, 972
@@ -216,6 +216,8 @@ def bind_prototypes(lib, prefix: str):
         lib.lg_policy_destroy.argtypes, lib.lg_policy_destroy.restype = [vp], None
         lib.lg_policy_act.argtypes = [vp, vp, vp, vp, i32, u64, i64, vp, i32, vp]
         lib.lg_policy_act.restype = C.c_int
+        lib.lg_policy_load_device.argtypes = [vp, vp, vp, vp, vp]
+        lib.lg_policy_load_device.restype = C.c_int
         lib.lg_step_policy.argtypes = [vp, vp, vp, vp, vp, u64, i32, i64, vp]
         lib.lg_step_policy.restype = C.c_int
         lib.lg_gae_returns.argtypes = [vp, vp, vp, vp, C.c_float, C.c_float, vp, vp, i32, i32, vp]
@@ -235,7 +237,7 @@ def bind_prototypes(lib, prefix: str):
 EXPORTED_SYMBOLS = ["lg_create", "lg_destroy", "lg_bind", "lg_step", "lg_reset_idx", "lg_actuator_forward",
                     "lg_physics_substep", "lg_compute_observations_only", "lg_set_params", "lg_last_error",
                     "lg_abi_version", "lg_sizeof", "lg_set_obs_buffer", "lg_policy_create", "lg_policy_destroy", "lg_policy_act",
-                    "lg_step_policy", "lg_gae_returns", "lg_ppo_loss"]
+                    "lg_step_policy", "lg_gae_returns", "lg_ppo_loss", "lg_policy_load_device"]
 
 
 def load_library():

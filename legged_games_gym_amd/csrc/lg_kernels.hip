@@ -1443,7 +1443,42 @@ static void policy_pack_layer(const float *W, const float *bias, int in_dim, int
     }
 }
 
+// device version of policy_pack_layer: one thread per packed element
+__global__ void k_policy_pack(const float *__restrict__ W, const float *__restrict__ bias, int in_dim, int out_dim, int in_tiles, int out_tiles,
+                              float *__restrict__ w_packed, float *__restrict__ b_packed) {
+    const size_t nw = (size_t)out_tiles * in_tiles * 4 * 64, nb = (size_t)out_tiles * 4 * 64;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nw + nb; i += (size_t)gridDim.x * blockDim.x) {
+        if (i < nw) {
+            const int l = (int)(i & 63), r = (int)((i >> 6) & 3);
+            const size_t ot = i >> 8;
+            const int t = (int)(ot % in_tiles), o = (int)(ot / in_tiles);
+            const int row = 16 * o + (l & 15), col = 16 * t + 4 * (l >> 4) + r;
+            w_packed[i] = (row < out_dim && col < in_dim) ? W[(size_t)row * in_dim + col] : 0.0f;
+        } else {
+            const size_t j = i - nw;
+            const int l = (int)(j & 63), r = (int)((j >> 6) & 3), o = (int)(j >> 8);
+            const int row = 16 * o + 4 * (l >> 4) + r;
+            b_packed[j] = row < out_dim ? bias[row] : 0.0f;
+        }
+    }
+}
+
 extern "C" {
+
+int lg_policy_load_device(lg_policy *p, const float *const weights[4], const float *const biases[4], const float *std, void *stream) {
+    if (!p || !weights || !biases || !std) return fail(-1, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    for (int i = 0; i < 4; i++) {
+        if (!weights[i] || !biases[i]) return fail(-1, "null layer pointer");
+        const int in_t = p->tiles[i], out_t = (i < 3) ? p->tiles[i + 1] : 1;
+        const size_t n = (size_t)out_t * in_t * 4 * 64 + (size_t)out_t * 4 * 64;
+        hipLaunchKernelGGL(k_policy_pack, dim3((unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256)), dim3(256), 0, st, weights[i], biases[i],
+                           p->dims[i], p->dims[i + 1], in_t, out_t, p->d_w[i], p->d_b[i]);
+    }
+    HIP_TRY(hipMemcpyAsync(p->d_std, std, p->dims[4] * sizeof(float), hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
 
 int lg_policy_create(const int32_t dims[5], const float *const weights[4], const float *const biases[4], const float *std,
                      int device_id, lg_policy **out) {

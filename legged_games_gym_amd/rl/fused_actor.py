@@ -52,6 +52,19 @@ class FusedActor:
             raise RuntimeError(f"lg_policy_create failed ({rc}): {self.lib.lg_last_error().decode()}")
         self.num_actions = lin[3].out_features
 
+    def sync_device(self):
+        """Refresh the kernel's weights from the torch parameters ON THE DEVICE (``lg_policy_load_device``): no host copy, no
+        synchronisation -- cheap enough to call after every PPO update."""
+        lin = self._layers()
+        ptr = C.c_void_p * 4
+        ws = ptr(*[m.weight.data_ptr() for m in lin]); bs = ptr(*[m.bias.data_ptr() for m in lin])
+        for m in lin:
+            if not (m.weight.is_contiguous() and m.weight.dtype == torch.float32 and m.weight.is_cuda):
+                raise ValueError("FusedActor.sync_device needs contiguous float32 CUDA parameters")
+        rc = self.lib.lg_policy_load_device(self.handle, ws, bs, self.ac.std.data_ptr(), torch.cuda.current_stream(self.device).cuda_stream)
+        if rc != 0:
+            raise RuntimeError(f"lg_policy_load_device failed ({rc}): {self.lib.lg_last_error().decode()}")
+
     def output_buffers(self, n):
         """(actions, mean) tensors the kernels write into (re-used between calls; clone to keep a value)."""
         if self._out is None or self._out[0].shape[0] != n:

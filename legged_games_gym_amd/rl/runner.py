@@ -31,10 +31,74 @@ class OnPolicyRunner:
         self.log_dir, self.writer = log_dir, None
         self.tot_timesteps, self.tot_time, self.current_learning_iteration = 0, 0.0, 0
         _, _ = self.env.reset()
+        self._fused = self._make_fused_actor()
+
+    def _make_fused_actor(self):
+        """Rollouts with the MFMA actor (and, for the flat task, the actor fused into the step kernel) instead of torch ops;
+        the critic, log-probs and the time-out bootstrap are then evaluated once per rollout on all T x N transitions."""
+        env = self.env
+        if not (str(self.device).startswith("cuda") and self.cfg.get("fused_rollout", True) and hasattr(env, "_sim")
+                and env.num_privileged_obs is None):
+            return None
+        try:
+            from .fused_actor import FusedActor
+            fused = FusedActor(self.alg.actor_critic, self.device, seed=int(getattr(env.cfg, "seed", 1)) + 7919,
+                               step_counter=env._sim.buf["step_counter"])
+        except Exception as exc:                              # unsupported actor shape: torch rollouts
+            print(f"[runner] MFMA actor unavailable ({type(exc).__name__}: {exc}); torch policy in the rollout")
+            return None
+        self._time_outs = torch.zeros(self.num_steps_per_env, env.num_envs, 1, device=self.device)
+        self._fused_step = None                               # decided at the first rollout: lg_step_policy or actor kernel + lg_step
+        return fused
+
+    def _fused_env_step(self, obs):
+        """One rollout step: ``lg_step_policy`` (actor inside the step kernel) where a fused kernel exists, else actor kernel + step."""
+        env, fused = self.env, self._fused
+        if self._fused_step is not False:
+            try:
+                (actions, mean), out = env.step_policy(fused)
+                self._fused_step = True
+                return actions, mean, out
+            except RuntimeError:
+                if self._fused_step:
+                    raise
+                self._fused_step = False                      # no fused kernel for this sim / actor pair
+        actions, mean = fused.act_with_mean(obs)
+        return actions, mean, env.step(actions)
+
+    def _rollout_steps_fused(self, stats):
+        env, alg, fused = self.env, self.alg, self._fused
+        st, T = alg.storage, self.num_steps_per_env
+        obs = env.get_observations()
+        for t in range(T):
+            st.observations[t].copy_(obs)
+            actions, mean, (obs, _, rewards, dones, infos) = self._fused_env_step(obs)
+            st.actions[t].copy_(actions); st.mu[t].copy_(mean)
+            st.rewards[t].copy_(rewards.view(-1, 1)); st.dones[t].copy_(dones.view(-1, 1))
+            if "time_outs" in infos:
+                self._time_outs[t].copy_(infos["time_outs"].view(-1, 1))
+            d = dones.float()
+            stats["cur_rew"] += rewards
+            stats["cur_len"] += 1.0
+            stats["sum_rew"] += (stats["cur_rew"] * d).sum()
+            stats["sum_len"] += (stats["cur_len"] * d).sum()
+            stats["count"] += d.sum()
+            stats["cur_rew"] *= 1.0 - d
+            stats["cur_len"] *= 1.0 - d
+        st.step = T
+        ac = alg.actor_critic
+        st.values.copy_(ac.evaluate(st.observations.flatten(0, 1)).view(T, -1, 1))            # critic once on all transitions
+        st.sigma.copy_(ac.std.detach().expand_as(st.sigma))
+        lp = torch.distributions.Normal(st.mu, st.sigma, validate_args=False).log_prob(st.actions).sum(dim=-1, keepdim=True)
+        st.actions_log_prob.copy_(lp)
+        st.rewards.add_(alg.gamma * st.values * self._time_outs)                               # bootstrap on time-outs (PPO.process_env_step)
+        return obs, obs
 
     # ------------------------------------------------------------------ graphed rollout
     def _rollout_steps(self, stats):
         """num_steps_per_env x (act -> env.step -> store); episode statistics as tensor ops (no host sync)."""
+        if self._fused is not None:
+            return self._rollout_steps_fused(stats)
         env, alg = self.env, self.alg
         obs = env.get_observations()
         pobs = env.get_privileged_observations()
@@ -136,6 +200,8 @@ class OnPolicyRunner:
                     t1 = time.time()
                     self.alg.compute_returns(cobs)
             mean_value_loss, mean_surrogate_loss = self.alg.update()
+            if self._fused is not None:
+                self._fused.sync_device()                     # the MFMA actor follows the optimiser (device-side repack)
             t2 = time.time()
             self.tot_timesteps += self.num_steps_per_env * self.env.num_envs
             self.tot_time += t2 - t0
@@ -163,6 +229,10 @@ class OnPolicyRunner:
         self.alg.actor_critic.load_state_dict(d["model_state_dict"])
         if load_optimizer:
             self.alg.optimizer.load_state_dict(d["optimizer_state_dict"])
+            if hasattr(self.alg, "after_optimizer_load"):
+                self.alg.after_optimizer_load()               # re-link the device learning rate, drop the captured update graph
+        if getattr(self, "_fused", None) is not None:
+            self._fused.sync_device()
         self.current_learning_iteration = d["iter"]
         return d["infos"]
 
