@@ -118,6 +118,30 @@ def test_fused_actor_matches_torch_forward():
         assert torch.allclose(fa.act_inference(obs), want2, atol=2e-5 * max(1.0, float(want2.abs().max())))
 
 
+def test_fused_actor_follows_the_optimiser_through_the_device_repack():
+    """lg_policy_load_device: after the torch parameters change, sync_device() (no host copy) must give the same actor as a
+    fresh host-side upload, for the flat and the wide shapes."""
+    from legged_games_gym_amd.rl import ActorCritic, FusedActor
+    for n_obs, hidden in ((48, [128, 64, 32]), (235, [512, 256, 128])):
+        torch.manual_seed(4)
+        ac = ActorCritic(n_obs, n_obs, 12, actor_hidden_dims=hidden, critic_hidden_dims=hidden, activation="elu").to("cuda")
+        fa = FusedActor(ac, "cuda:0", seed=1)
+        with torch.no_grad():
+            for prm in ac.parameters():
+                prm.add_(0.05 * torch.randn_like(prm))
+            ac.std.mul_(0.7)
+        fa.sync_device()
+        obs = torch.randn(333, n_obs, device="cuda")
+        got = fa.act_inference(obs).clone()
+        want = ac.act_inference(obs).detach()
+        assert float((got - want).abs().max()) < 2e-5 * max(1.0, float(want.abs().max()))
+        fb = FusedActor(ac, "cuda:0", seed=1)                 # host-side pack of the same parameters
+        assert torch.equal(fb.act_inference(obs), got)
+        a1, m1 = fa.act_with_mean(obs); a1 = a1.clone()
+        a2, m2 = fb.act_with_mean(obs)
+        assert torch.equal(a1, a2)                            # same std, same noise stream
+
+
 def test_fused_policy_step_equals_actor_kernel_plus_step():
     """lg_step_policy (actor inside the step kernel) == lg_policy_act followed by lg_step on the same state and noise stream."""
     from legged_games_gym_amd.rl import ActorCritic, FusedActor
