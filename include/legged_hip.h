@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LG_ABI_VERSION        12
+#define LG_ABI_VERSION        13
 
 #define LG_MAX_LIMBS          4
 #define LG_MAX_CHAIN          6
@@ -224,6 +224,31 @@ int  lg_step_policy(lg_sim *sim, lg_policy *p, const float *obs, float *actions,
  * values (un-normalised: the caller normalises over the global batch).  Device pointers, asynchronous on `stream`. */
 int  lg_gae_returns(const float *rewards, const float *values, const uint8_t *dones, const float *last_values, float gamma, float lam,
                     float *returns, float *advantages, int32_t num_steps, int32_t num_envs, void *stream);
+
+/* One ActorCritic MLP (Linear/ELU x3 + Linear; rsl_rl ActorCritic.actor / .critic, [EXTERNAL], widths from
+ * legged_robot_config.py:204-209) for the learner kernels below.  weights[l] is torch's nn.Linear weight [dims[l+1], dims[l]]
+ * row-major, biases[l] its bias; all device pointers. */
+typedef struct lg_mlp_net {
+    const float *weights[4];
+    const float *biases[4];
+    float       *grad_weights[4];   /* lg_mlp_backward outputs (same layouts), overwritten */
+    float       *grad_biases[4];
+    const float *input;             /* [R, dims[0]] rows (e.g. the flattened rollout storage) */
+    float       *output;            /* lg_mlp_forward: [mb, dims[4]] */
+    const float *grad_output;       /* lg_mlp_backward: dL/d output [mb, dims[4]] */
+    int32_t      dims[5];
+} lg_mlp_net;
+
+/* Mini-batch forward of 1 or 2 MLPs on the matrix cores: output[i] = net(input[rows[i]]) (rows == NULL: input[i]), i < mb.
+ * This is what `actor(obs_batch)` / `critic(critic_obs_batch)` compute inside rsl_rl PPO.update() ([EXTERNAL]).
+ * Returns -4 for MLP shapes that are not built (callers then keep their autograd path).  Asynchronous, capturable. */
+int  lg_mlp_forward(const lg_mlp_net *nets, int32_t n_nets, const int64_t *rows, int32_t mb, void *stream);
+/* Gradients of all weights and biases given dL/d output, i.e. what loss.backward() leaves in .grad for these modules
+ * (forward activations are recomputed in LDS, nothing is stored between the two calls).  `workspace` holds per-workgroup
+ * partial sums (lg_mlp_workspace_bytes); the reduction order is fixed, so results are bit-reproducible. */
+size_t lg_mlp_workspace_bytes(const lg_mlp_net *nets, int32_t n_nets);
+int  lg_mlp_backward(const lg_mlp_net *nets, int32_t n_nets, const int64_t *rows, int32_t mb, float *workspace, size_t workspace_bytes,
+                     void *stream);
 
 /* Fused PPO loss and its gradient w.r.t. the network outputs for one mini-batch (rsl_rl PPO.update's surrogate / clipped value /
  * entropy terms and the adaptive-KL statistic, [EXTERNAL]; hyper-parameters legged_robot_config.py:215-228):

@@ -16,7 +16,7 @@ from typing import Dict, Optional
 
 import numpy as np
 
-LG_ABI_VERSION = 12
+LG_ABI_VERSION = 13
 LG_MAX_LIMBS, LG_MAX_CHAIN, LG_MAX_DOF = 4, 6, 12
 LG_MAX_LIMB_POINTS, LG_MAX_BASE_POINTS, LG_MAX_BODIES = 8, 4, 20
 LG_MAX_HEIGHT_POINTS, LG_ACTUATOR_FLOATS = 192, 972
@@ -174,6 +174,12 @@ def pack_model(model, foot_name: str, penalize_on, terminate_on, armature: float
     return m
 
 
+class lg_mlp_net(C.Structure):
+    """include/legged_hip.h: lg_mlp_net (device pointers as integers)."""
+    _fields_ = [("weights", C.c_void_p * 4), ("biases", C.c_void_p * 4), ("grad_weights", C.c_void_p * 4), ("grad_biases", C.c_void_p * 4),
+                ("input", C.c_void_p), ("output", C.c_void_p), ("grad_output", C.c_void_p), ("dims", i32 * 5)]
+
+
 def struct_to_dict(s) -> Dict:
     out = {}
     for name, _ in s._fields_:
@@ -224,6 +230,12 @@ def bind_prototypes(lib, prefix: str):
         lib.lg_gae_returns.restype = C.c_int
         lib.lg_ppo_loss.argtypes = [vp] * 11 + [C.c_float, C.c_float, C.c_float, i32, vp, vp, vp, vp, i32, i32, vp]
         lib.lg_ppo_loss.restype = C.c_int
+        lib.lg_mlp_forward.argtypes = [C.POINTER(lg_mlp_net), i32, vp, i32, vp]
+        lib.lg_mlp_forward.restype = C.c_int
+        lib.lg_mlp_workspace_bytes.argtypes = [C.POINTER(lg_mlp_net), i32]
+        lib.lg_mlp_workspace_bytes.restype = C.c_size_t
+        lib.lg_mlp_backward.argtypes = [C.POINTER(lg_mlp_net), i32, vp, i32, vp, C.c_size_t, vp]
+        lib.lg_mlp_backward.restype = C.c_int
     for name, (args, res) in sig.items():
         fn = getattr(lib, prefix + name)
         fn.argtypes, fn.restype = args, res
@@ -237,7 +249,8 @@ def bind_prototypes(lib, prefix: str):
 EXPORTED_SYMBOLS = ["lg_create", "lg_destroy", "lg_bind", "lg_step", "lg_reset_idx", "lg_actuator_forward",
                     "lg_physics_substep", "lg_compute_observations_only", "lg_set_params", "lg_last_error",
                     "lg_abi_version", "lg_sizeof", "lg_set_obs_buffer", "lg_policy_create", "lg_policy_destroy", "lg_policy_act",
-                    "lg_step_policy", "lg_gae_returns", "lg_ppo_loss", "lg_policy_load_device"]
+                    "lg_step_policy", "lg_gae_returns", "lg_ppo_loss", "lg_policy_load_device", "lg_mlp_forward",
+                    "lg_mlp_workspace_bytes", "lg_mlp_backward"]
 
 
 def load_library():

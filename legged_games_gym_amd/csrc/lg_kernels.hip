@@ -18,6 +18,7 @@
 
 #include "lg_device.h"
 #include "lg_policy.h"
+#include "lg_train.h"
 
 using namespace lg;
 
@@ -1462,6 +1463,83 @@ __global__ void k_policy_pack(const float *__restrict__ W, const float *__restri
         }
     }
 }
+
+// ---- PPO learner: MLP forward / backward for up to two nets (actor, critic) in one launch -------------------------------------
+#define LG_TRAIN_WGS 256           /* workgroups per net = partial-sum slices */
+static int mlp_fill(const lg_mlp_net *nets, int32_t n_nets, const int64_t *rows, int32_t mb, lg::MlpArgs &a, int &wgs) {
+    if (!nets || n_nets < 1 || n_nets > 2 || mb <= 0) return fail(-1, "bad argument");
+    memset(&a, 0, sizeof a);
+    a.rows = rows; a.mb = mb; a.n_tiles = (mb + 15) / 16;
+    wgs = a.n_tiles < LG_TRAIN_WGS ? a.n_tiles : LG_TRAIN_WGS;
+    for (int n = 0; n < n_nets; n++) {
+        const lg_mlp_net &s = nets[n];
+        lg::MlpNetArgs &d = a.net[n];
+        if (!s.input) return fail(-1, "null input");
+        if (s.dims[0] <= 0 || s.dims[0] > 48 || s.dims[1] != 128 || s.dims[2] != 64 || s.dims[3] != 32 || s.dims[4] <= 0 || s.dims[4] > 16)
+            return fail(-4, "lg_mlp_*: only the <=48-128-64-32-<=16 MLP shape is built");
+        int gf = 0;
+        for (int l = 0; l < 4; l++) {
+            if (!s.weights[l] || !s.biases[l]) return fail(-1, "null layer pointer");
+            if (l > 0 && ((uintptr_t)s.weights[l] & 15)) return fail(-4, "weights must be 16-byte aligned");
+            d.w[l] = s.weights[l]; d.b[l] = s.biases[l];
+            gf += s.dims[l + 1] * s.dims[l] + s.dims[l + 1];
+        }
+        d.x = s.input; d.y = s.output; d.dy = s.grad_output; d.grad_floats = gf;
+        memcpy(d.dims, s.dims, sizeof d.dims);
+    }
+    return 0;
+}
+
+extern "C" {
+
+int lg_mlp_forward(const lg_mlp_net *nets, int32_t n_nets, const int64_t *rows, int32_t mb, void *stream) {
+    lg::MlpArgs a; int wgs;
+    if (int rc = mlp_fill(nets, n_nets, rows, mb, a, wgs)) return rc;
+    for (int n = 0; n < n_nets; n++) if (!nets[n].output) return fail(-1, "null output");
+    hipLaunchKernelGGL((lg::k_mlp_train<3, 8, 4, 2, false>), dim3(a.n_tiles < 2048 ? a.n_tiles : 2048, n_nets), dim3(64 * LG_TRAIN_WAVES), 0,
+                       (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+size_t lg_mlp_workspace_bytes(const lg_mlp_net *nets, int32_t n_nets) {
+    size_t total = 0;
+    if (!nets) return 0;
+    for (int n = 0; n < n_nets; n++) {
+        size_t gf = 0;
+        for (int l = 0; l < 4; l++) gf += (size_t)nets[n].dims[l + 1] * nets[n].dims[l] + nets[n].dims[l + 1];
+        total += gf * LG_TRAIN_WGS * sizeof(float);
+    }
+    return total;
+}
+
+int lg_mlp_backward(const lg_mlp_net *nets, int32_t n_nets, const int64_t *rows, int32_t mb, float *workspace, size_t workspace_bytes,
+                    void *stream) {
+    lg::MlpArgs a; int wgs;
+    if (int rc = mlp_fill(nets, n_nets, rows, mb, a, wgs)) return rc;
+    if (!workspace || workspace_bytes < lg_mlp_workspace_bytes(nets, n_nets)) return fail(-1, "workspace too small (lg_mlp_workspace_bytes)");
+    lg::MlpReduceArgs r; memset(&r, 0, sizeof r);
+    float *ws = workspace;
+    int max_gf = 0;
+    for (int n = 0; n < n_nets; n++) {
+        if (!nets[n].grad_output) return fail(-1, "null grad_output");
+        a.net[n].partial = ws; r.partial[n] = ws; ws += (size_t)a.net[n].grad_floats * LG_TRAIN_WGS;
+        r.grad_floats[n] = a.net[n].grad_floats; if (a.net[n].grad_floats > max_gf) max_gf = a.net[n].grad_floats;
+        memcpy(r.dims[n], nets[n].dims, sizeof r.dims[n]);
+        for (int l = 0; l < 4; l++) {
+            if (!nets[n].grad_weights[l] || !nets[n].grad_biases[l]) return fail(-1, "null gradient pointer");
+            r.gw[n][l] = nets[n].grad_weights[l]; r.gb[n][l] = nets[n].grad_biases[l];
+        }
+    }
+    r.n_partials = wgs;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL((lg::k_mlp_train<3, 8, 4, 2, true>), dim3(wgs, n_nets), dim3(64 * LG_TRAIN_WAVES), 0, st, a);
+    hipLaunchKernelGGL(lg::k_mlp_reduce, dim3((max_gf + 255) / 256, n_nets), dim3(256), 0, st, r);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"
 
 extern "C" {
 

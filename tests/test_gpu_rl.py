@@ -101,3 +101,44 @@ def test_graph_captured_update_equals_the_eager_update():
         assert abs(ve - vg) < 2e-5 and abs(se - sg) < 2e-5
     for a, b in zip(p_e, p_g):
         assert float((a - b).abs().max()) < 1e-4          # fused loss kernel vs torch loss: rounding, amplified by three Adam updates
+
+
+def _mlp(i, o, seed):
+    import torch.nn as nn
+    torch.manual_seed(seed)
+    return nn.Sequential(nn.Linear(i, 128), nn.ELU(), nn.Linear(128, 64), nn.ELU(), nn.Linear(64, 32), nn.ELU(), nn.Linear(32, o)).cuda()
+
+
+@pytest.mark.parametrize("mb,gather", [(1000, True), (24576, True), (37, False)])
+def test_mlp_kernels_match_autograd(mb, gather):
+    """lg_mlp_forward / lg_mlp_backward (MFMA learner kernels) against torch autograd on the same nn.Sequential modules."""
+    from legged_games_gym_amd.rl.mlp_kernels import MlpTrainer
+    actor, critic = _mlp(48, 12, 0), _mlp(48, 1, 1)
+    R = 30000
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(R, 48, device="cuda", generator=g)
+    rows = torch.randperm(R, device="cuda", generator=g)[:mb] if gather else None
+    tr = MlpTrainer([actor, critic], [x, x], mb)
+    assert tr.supported
+    mu, val = tr.forward(rows)
+    xb = x[rows] if gather else x[:mb]
+    mu_ref, val_ref = actor(xb), critic(xb)
+    assert float((mu - mu_ref.detach()).abs().max()) < 2e-5 and float((val - val_ref.detach()).abs().max()) < 2e-5
+    d_mu = torch.randn(mb, 12, device="cuda", generator=g) / mb
+    d_val = torch.randn(mb, 1, device="cuda", generator=g) / mb
+    torch.autograd.backward([mu_ref, val_ref], [d_mu, d_val])
+    want = [p.grad.clone() for net in (actor, critic) for p in net.parameters()]
+    for net in (actor, critic):
+        for p in net.parameters():
+            p.grad.fill_(float("nan"))                   # the kernel overwrites every element
+    tr.refresh()
+    tr.grad_outputs[0].copy_(d_mu); tr.grad_outputs[1].copy_(d_val)
+    tr.backward(rows)
+    got = [p.grad for net in (actor, critic) for p in net.parameters()]
+    for w, h in zip(want, got):
+        scale = float(w.abs().max()) + 1e-12
+        assert float((w - h).abs().max()) < 2e-4 * scale + 1e-9, (w.shape, float((w - h).abs().max()), scale)
+    # fixed reduction order: bit-reproducible
+    first = [h.clone() for h in got]
+    tr.backward(rows)
+    assert all(torch.equal(a, b) for a, b in zip(first, got))
