@@ -136,6 +136,10 @@ class PPO:
         # (``lg_ppo_loss``) instead of ~100 small torch kernels; autograd only runs through the two MLPs.
         import os as _os
         self._fused_loss = bool(fused_loss) and self._graph_ok and _os.environ.get("LG_PPO_FUSED_LOSS", "1") != "0"
+        # ... and for the MLP shape of the flat tasks the two networks' forward and backward run in the MFMA learner kernels
+        # (lg_mlp_forward / lg_mlp_backward, rl/mlp_kernels.py): autograd is not involved at all.  LG_PPO_MLP_KERNELS=0 disables.
+        self._mlp_kernels = self._fused_loss and _os.environ.get("LG_PPO_MLP_KERNELS", "1") != "0"
+        self._mlp = None
         self._lib = None
         self.desired_kl, self.schedule, self.learning_rate = desired_kl, schedule, learning_rate
         self.actor_critic = actor_critic.to(device)
@@ -231,22 +235,49 @@ class PPO:
         ac = self.actor_critic
         return bool(self._lib) and hasattr(ac, "actor") and hasattr(ac, "critic") and hasattr(ac, "std") and ac.std.numel() <= 16
 
+    def _mlp_trainer(self):
+        """MlpTrainer for the current storage / mini-batch size, or None when the networks are not the kernels' shape."""
+        if not self._mlp_kernels:
+            return None
+        st, ac = self.storage, self.actor_critic
+        obs = st.observations.flatten(0, 1)
+        cobs = st.privileged_observations.flatten(0, 1) if st.privileged_observations is not None else obs
+        mb = self._ix.numel()
+        key = (obs.data_ptr(), cobs.data_ptr(), mb)
+        if self._mlp is None or self._mlp_key != key:
+            from .mlp_kernels import MlpTrainer
+            if not (isinstance(ac.actor, nn.Sequential) and isinstance(ac.critic, nn.Sequential)):
+                self._mlp_kernels = False
+                return None
+            self._mlp, self._mlp_key = MlpTrainer([ac.actor, ac.critic], [obs, cobs], mb), key
+            if not self._mlp.supported:
+                self._mlp_kernels, self._mlp = False, None
+                return None
+        return self._mlp
+
     def _mb_step_fused(self):
-        """Mini-batch step with the fused loss kernel: MLP forward (torch) -> lg_ppo_loss -> MLP backward (autograd) -> clip -> Adam."""
+        """Mini-batch step with the fused loss kernel: MLP forward -> lg_ppo_loss -> MLP backward -> clip -> Adam.  The MLP
+        passes are the MFMA learner kernels when the networks have their shape, torch (autograd) otherwise."""
         st, ac, ix = self.storage, self.actor_critic, self._ix
-        obs_all = st.observations.flatten(0, 1)
-        obs = obs_all[ix]
-        cobs = st.privileged_observations.flatten(0, 1)[ix] if st.privileged_observations is not None else obs
-        mu = ac.actor(obs)
-        val = ac.critic(cobs)
+        tr = self._mlp_trainer()
+        if tr is not None:
+            tr.refresh()                             # parameter / .grad addresses (stable in steady state)
+            mu, val = tr.forward(ix)
+        else:
+            obs_all = st.observations.flatten(0, 1)
+            obs = obs_all[ix]
+            cobs = st.privileged_observations.flatten(0, 1)[ix] if st.privileged_observations is not None else obs
+            mu = ac.actor(obs)
+            val = ac.critic(cobs)
         mb, A = mu.shape
         if getattr(self, "_d_mu", None) is None or self._d_mu.shape != mu.shape:
             self._d_mu, self._d_val = torch.empty_like(mu), torch.empty(mb, 1, device=mu.device)
             self._d_std, self._stats = torch.zeros(A, device=mu.device), torch.zeros(4, device=mu.device)
+        d_mu, d_val = (tr.grad_outputs if tr is not None else (self._d_mu, self._d_val))
         p = lambda t: t.data_ptr()
         rc = self._lib.lg_ppo_loss(p(mu), p(ac.std), p(val), p(ix), p(st.actions), p(st.actions_log_prob), p(st.mu), p(st.sigma), p(st.advantages),
                                    p(st.values), p(st.returns), float(self.clip_param), float(self.value_loss_coef), float(self.entropy_coef),
-                                   int(bool(self.use_clipped_value_loss)), p(self._d_mu), p(self._d_std), p(self._d_val), p(self._stats), int(mb), int(A),
+                                   int(bool(self.use_clipped_value_loss)), p(d_mu), p(self._d_std), p(d_val), p(self._stats), int(mb), int(A),
                                    torch.cuda.current_stream(mu.device).cuda_stream)
         if rc != 0:
             raise RuntimeError(f"lg_ppo_loss failed ({rc}): {self._lib.lg_last_error().decode()}")
@@ -255,13 +286,21 @@ class PPO:
                 kl, lr = self._stats[2], self._lr
                 down, up = torch.clamp(lr / 1.5, min=1e-5), torch.clamp(lr * 1.5, max=1e-2)
                 self._lr.copy_(torch.where(kl > self.desired_kl * 2.0, down, torch.where((kl < self.desired_kl / 2.0) & (kl > 0.0), up, lr)))
-        torch.autograd.backward([mu, val], [self._d_mu, self._d_val])
+        if tr is not None:
+            tr.backward(ix)
+        else:
+            torch.autograd.backward([mu, val], [d_mu, d_val])
         ac.std.grad = self._d_std
         nn.utils.clip_grad_norm_(ac.parameters(), self.max_grad_norm)
         self.optimizer.step()
         with torch.no_grad():
             self._acc[0] += self._stats[1]
             self._acc[1] += self._stats[0]
+
+    def _zero_grad(self):
+        # the learner kernels overwrite persistent .grad tensors (their addresses are baked into the captured graph)
+        if not (self._mlp_kernels and self._mlp is not None):
+            self.optimizer.zero_grad(set_to_none=True)
 
     def _mb_step(self):
         """One mini-batch step on the rows listed in ``self._ix``; everything stays on the device (no host decisions)."""
@@ -302,7 +341,8 @@ class PPO:
         mb = B // self.num_mini_batches
         key = (st.observations.data_ptr(), st.advantages.data_ptr(), st.returns.data_ptr(), mb)
         if self._graph is not None and key != self._graph_key:
-            self._graph = None                      # the storage was re-allocated: the captured graph reads the old buffers
+            # the storage was re-allocated: the captured graph reads the old buffers; warm up eagerly again before re-capturing
+            self._graph, self._mlp, self._updates_done = None, None, 0
         self._graph_key = key
         if self._graph is None and (not hasattr(self, "_ix") or self._ix.numel() != mb):
             self._ix = torch.zeros(mb, dtype=torch.int64, device=self.device)
@@ -324,7 +364,7 @@ class PPO:
                     continue
                 self._gstream.wait_stream(cur)
                 if capture_now:
-                    self.optimizer.zero_grad(set_to_none=True)
+                    self._zero_grad()
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, stream=self._gstream):
                         self._mb_step()
@@ -333,7 +373,7 @@ class PPO:
                     g.replay()                               # the capture did not execute: run this mini-batch now
                 else:
                     with torch.cuda.stream(self._gstream):
-                        self.optimizer.zero_grad(set_to_none=True)
+                        self._zero_grad()
                         self._mb_step()
                     cur.wait_stream(self._gstream)
         n = self.num_learning_epochs * self.num_mini_batches
