@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LG_ABI_VERSION        13
+#define LG_ABI_VERSION        14
 
 #define LG_MAX_LIMBS          4
 #define LG_MAX_CHAIN          6
@@ -249,6 +249,24 @@ int  lg_mlp_forward(const lg_mlp_net *nets, int32_t n_nets, const int64_t *rows,
 size_t lg_mlp_workspace_bytes(const lg_mlp_net *nets, int32_t n_nets);
 int  lg_mlp_backward(const lg_mlp_net *nets, int32_t n_nets, const int64_t *rows, int32_t mb, float *workspace, size_t workspace_bytes,
                      void *stream);
+
+/* One parameter tensor of torch.optim.Adam(capturable=True): the parameter, its .grad and the optimiser state
+ * (state['exp_avg'], state['exp_avg_sq'], state['step'] -- a float32 device scalar).  All updated in place. */
+typedef struct lg_adam_tensor {
+    float       *param;
+    const float *grad;
+    float       *exp_avg;
+    float       *exp_avg_sq;
+    float       *step;
+    int64_t      numel;
+} lg_adam_tensor;
+
+/* The tail of rsl_rl PPO.update()'s mini-batch step ([EXTERNAL]) in two launches: nn.utils.clip_grad_norm_(params, max_grad_norm)
+ * over all `tensors` together, the adaptive-KL learning-rate rule (kl == NULL or desired_kl <= 0: fixed schedule;
+ * legged_robot_config.py:221-226) on the device scalar `lr`, and torch.optim.Adam.step() (weight_decay 0, amsgrad off) on the
+ * clipped gradients.  scratch [2] receives {total gradient norm, clip coefficient}.  n_tensors <= 32.  Capturable. */
+int  lg_adam_step(const lg_adam_tensor *tensors, int32_t n_tensors, float *lr, float beta1, float beta2, float eps, float max_grad_norm,
+                  const float *kl, float desired_kl, float *scratch, void *stream);
 
 /* Fused PPO loss and its gradient w.r.t. the network outputs for one mini-batch (rsl_rl PPO.update's surrogate / clipped value /
  * entropy terms and the adaptive-KL statistic, [EXTERNAL]; hyper-parameters legged_robot_config.py:215-228):

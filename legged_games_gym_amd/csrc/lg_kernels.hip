@@ -1470,7 +1470,17 @@ static int mlp_fill(const lg_mlp_net *nets, int32_t n_nets, const int64_t *rows,
     if (!nets || n_nets < 1 || n_nets > 2 || mb <= 0) return fail(-1, "bad argument");
     memset(&a, 0, sizeof a);
     a.rows = rows; a.mb = mb; a.n_tiles = (mb + 15) / 16;
-    wgs = a.n_tiles < LG_TRAIN_WGS ? a.n_tiles : LG_TRAIN_WGS;
+    // persistent workgroups, one per CU (the LDS-resident weights allow no more): the CUs are split between the nets
+    static int num_cus = 0;
+    if (!num_cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || num_cus <= 0)
+            num_cus = 256;
+    }
+    wgs = num_cus / n_nets;
+    if (wgs > LG_TRAIN_WGS) wgs = LG_TRAIN_WGS;
+    if (wgs > a.n_tiles) wgs = a.n_tiles;
+    if (wgs < 1) wgs = 1;
     for (int n = 0; n < n_nets; n++) {
         const lg_mlp_net &s = nets[n];
         lg::MlpNetArgs &d = a.net[n];
@@ -1496,8 +1506,13 @@ int lg_mlp_forward(const lg_mlp_net *nets, int32_t n_nets, const int64_t *rows, 
     lg::MlpArgs a; int wgs;
     if (int rc = mlp_fill(nets, n_nets, rows, mb, a, wgs)) return rc;
     for (int n = 0; n < n_nets; n++) if (!nets[n].output) return fail(-1, "null output");
-    hipLaunchKernelGGL((lg::k_mlp_train<3, 8, 4, 2, false>), dim3(a.n_tiles < 2048 ? a.n_tiles : 2048, n_nets), dim3(64 * LG_TRAIN_WAVES), 0,
-                       (hipStream_t)stream, a);
+    constexpr size_t lds_bytes = lg::TrainLds<3, 8, 4, 2, false>::floats * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void *)lg::k_mlp_train<3, 8, 4, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((lg::k_mlp_train<3, 8, 4, 2, false>), dim3(wgs, n_nets), dim3(64 * LG_TRAIN_WAVES), lds_bytes, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1533,8 +1548,35 @@ int lg_mlp_backward(const lg_mlp_net *nets, int32_t n_nets, const int64_t *rows,
     }
     r.n_partials = wgs;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL((lg::k_mlp_train<3, 8, 4, 2, true>), dim3(wgs, n_nets), dim3(64 * LG_TRAIN_WAVES), 0, st, a);
+    constexpr size_t lds_bytes = lg::TrainLds<3, 8, 4, 2, true>::floats * sizeof(float);
+    static_assert(lds_bytes <= 160 * 1024, "k_mlp_train backward exceeds the CU's LDS");
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void *)lg::k_mlp_train<3, 8, 4, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((lg::k_mlp_train<3, 8, 4, 2, true>), dim3(wgs, n_nets), dim3(64 * LG_TRAIN_WAVES), lds_bytes, st, a);
     hipLaunchKernelGGL(lg::k_mlp_reduce, dim3((max_gf + 255) / 256, n_nets), dim3(256), 0, st, r);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int lg_adam_step(const lg_adam_tensor *tensors, int32_t n_tensors, float *lr, float beta1, float beta2, float eps, float max_grad_norm,
+                 const float *kl, float desired_kl, float *scratch, void *stream) {
+    if (!tensors || !lr || !scratch || n_tensors < 1 || n_tensors > LG_ADAM_MAX_TENSORS) return fail(-1, "bad argument");
+    lg::AdamArgs a; memset(&a, 0, sizeof a);
+    int64_t max_n = 0;
+    for (int k = 0; k < n_tensors; k++) {
+        const lg_adam_tensor &t = tensors[k];
+        if (!t.param || !t.grad || !t.exp_avg || !t.exp_avg_sq || !t.step || t.numel <= 0) return fail(-1, "incomplete optimiser tensor");
+        a.t[k] = lg::AdamTensor{t.param, t.grad, t.exp_avg, t.exp_avg_sq, t.step, t.numel};
+        if (t.numel > max_n) max_n = t.numel;
+    }
+    a.n_tensors = n_tensors; a.lr = lr; a.kl = kl; a.scratch = scratch;
+    a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.max_norm = max_grad_norm; a.desired_kl = desired_kl;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(lg::k_adam_prepare, dim3(1), dim3(1024), 0, st, a);
+    hipLaunchKernelGGL(lg::k_adam_update, dim3((unsigned)((max_n + 255) / 256), n_tensors), dim3(256), 0, st, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }

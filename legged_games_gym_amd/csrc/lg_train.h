@@ -3,8 +3,10 @@
 // Stands in for the autograd pass over rsl_rl's ActorCritic MLPs ([EXTERNAL]; Linear/ELU x3 + Linear, dims from reference
 // legged_robot_config.py:204-209) inside PPO.update(): y = net(x[rows]) and, given dL/dy, the gradients of all weights
 // and biases.  The weights are read in torch's own [out, in] layout (they change every optimiser step, so nothing is
-// re-packed), activations never leave LDS, and the weight gradients are accumulated in MFMA accumulators across all the
-// row tiles a workgroup walks, then written once as a per-workgroup partial that k_mlp_reduce sums in a fixed order
+// re-packed): each persistent workgroup copies them ONCE into LDS (72 KB, rows padded by 4 floats against bank conflicts)
+// and then walks its row tiles with every operand coming from LDS -- a wave per SIMD cannot hide L2 latency eight times
+// per row tile.  Activations never leave LDS, and the weight gradients are accumulated in MFMA accumulators across all
+// the row tiles a workgroup walks, then written once as a per-workgroup partial that k_mlp_reduce sums in a fixed order
 // (deterministic, no atomics).
 //
 // Tile algebra (v_mfma_f32_16x16x4_f32, D[i][j] += A[i][k] B[k][j]; A: lane l holds A[l&15][l>>4], B: lane l holds
@@ -20,7 +22,8 @@
 namespace lg {
 
 #define LG_TRAIN_WAVES 4
-#define LG_TT 17                       // padded row stride of the feature-major tile copies (bank-conflict free)
+#define LG_TT 20                       // row stride of the feature-major tile copies: 16-byte aligned quads, <= 2-way bank conflicts
+#define LG_WPAD 4                      // padding floats per weight row in LDS
 
 struct MlpNetArgs {
     const float *w[4], *b[4];          // torch Linear weights [out, in] / biases
@@ -37,79 +40,98 @@ struct MlpArgs {
     int32_t mb, n_tiles;
 };
 
+// LDS image of one Linear layer: rows 16*OUT_T (zero beyond out_dim), IN_T*16 columns (zero beyond in_dim) + LG_WPAD, then the bias
+template <int IN_T, int OUT_T> struct LdsLayer {
+    static constexpr int stride = 16 * IN_T + LG_WPAD, w_floats = 16 * OUT_T * stride, floats = w_floats + 16 * OUT_T;
+};
+template <int IN_T, int OUT_T>
+LG_DEV void lds_layer_fill(float *wl, const float *__restrict__ W, const float *__restrict__ b, int in_dim, int out_dim, int tid) {
+    using L = LdsLayer<IN_T, OUT_T>;
+    constexpr int QPR = 4 * IN_T, NQ = 16 * OUT_T * QPR, NT = 64 * LG_TRAIN_WAVES;     // quads per row / in the layer
+    const bool vec = (in_dim & 3) == 0;
+    // batches of 4 quads per thread: all the loads of a batch are in flight before the first LDS store needs one
+#pragma unroll 1
+    for (int i0 = tid; i0 < NQ; i0 += 4 * NT) {
+        float4 q[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + u * NT, row = i / QPR, col = 4 * (i % QPR);
+            q[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < NQ && row < out_dim) {
+                const float *src = W + (size_t)row * in_dim + col;
+                if (vec && col + 3 < in_dim) q[u] = *reinterpret_cast<const float4 *>(src);
+                else {
+                    if (col + 0 < in_dim) q[u].x = src[0];
+                    if (col + 1 < in_dim) q[u].y = src[1];
+                    if (col + 2 < in_dim) q[u].z = src[2];
+                    if (col + 3 < in_dim) q[u].w = src[3];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + u * NT, row = i / QPR, col = 4 * (i % QPR);
+            if (i < NQ) *reinterpret_cast<float4 *>(wl + row * L::stride + col) = q[u];
+        }
+    }
+    for (int i = tid; i < 16 * OUT_T; i += NT) wl[L::w_floats + i] = i < out_dim ? b[i] : 0.0f;
+}
+
 // feature-major copy of a tile: xt[feature 16][LG_TT] <- lane (row l&15, group g) holds features 4g..4g+3
-LG_DEV void tile_store(float4 (*x)[64], float (*xt)[16][LG_TT], int tile, int lane, float4 v) {
-    x[tile][lane] = v;
+LG_DEV void tile_store_t(float (*xt)[16][LG_TT], int tile, int lane, float4 v) {
     const int g = lane >> 4, r = lane & 15;
     xt[tile][4 * g + 0][r] = v.x; xt[tile][4 * g + 1][r] = v.y; xt[tile][4 * g + 2][r] = v.z; xt[tile][4 * g + 3][r] = v.w;
 }
 
-// x_out = act(W x_in + b); W [out_dim, in_dim] row-major.  FIRST: in_dim is arbitrary (guarded scalar loads), otherwise a
-// multiple of 16 (float4 loads).
-template <int IN_T, int OUT_T, bool ACT, bool FIRST, bool KEEP_T>
-LG_DEV void train_forward_layer(const float *__restrict__ W, const float *__restrict__ b, int in_dim, int out_dim,
-                                const float4 (*xin)[64], float4 (*xout)[64], float (*xoutT)[16][LG_TT], int wave, int lane) {
+// x_out = act(W x_in + b), all operands in LDS
+template <int IN_T, int OUT_T, bool ACT, bool KEEP_T>
+LG_DEV void train_forward_layer(const float *wl, const float4 (*xin)[64], float4 (*xout)[64], float (*xoutT)[16][LG_TT], int wave, int lane) {
+    using L = LdsLayer<IN_T, OUT_T>;
     const int g = lane >> 4;
 #pragma unroll 1
     for (int o = wave; o < OUT_T; o += LG_TRAIN_WAVES) {
-        const int row = 16 * o + (lane & 15);
-        const bool rok = row < out_dim;
-        const float *wr = W + (size_t)(rok ? row : 0) * in_dim + 4 * g;
-        float4 wv[IN_T];
+        const float *wr = wl + (16 * o + (lane & 15)) * L::stride + 4 * g;
+        const float4 bv = *reinterpret_cast<const float4 *>(wl + L::w_floats + 16 * o + 4 * g);
+        f32x4 acc = {bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
         for (int t = 0; t < IN_T; t++) {
-            if (FIRST) {
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; r++) { const int k = 16 * t + 4 * g + r; v[r] = (rok && k < in_dim) ? wr[16 * t + r] : 0.0f; }
-                wv[t] = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-                wv[t] = rok ? *reinterpret_cast<const float4 *>(wr + 16 * t) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
-        f32x4 acc;
-#pragma unroll
-        for (int r = 0; r < 4; r++) { const int f = 16 * o + 4 * g + r; acc[r] = f < out_dim ? b[f] : 0.0f; }
-#pragma unroll
-        for (int t = 0; t < IN_T; t++) {
+            const float4 wv = *reinterpret_cast<const float4 *>(wr + 16 * t);
             const float4 xv = xin[t][lane];
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[t].x, xv.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[t].y, xv.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[t].z, xv.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[t].w, xv.w, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.x, xv.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.y, xv.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.z, xv.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.w, xv.w, acc, 0, 0, 0);
         }
         const float4 res = ACT ? make_float4(elu1(acc[0]), elu1(acc[1]), elu1(acc[2]), elu1(acc[3])) : make_float4(acc[0], acc[1], acc[2], acc[3]);
-        if (KEEP_T) tile_store(xout, xoutT, o, lane, res); else xout[o][lane] = res;
+        xout[o][lane] = res;
+        if (KEEP_T) tile_store_t(xoutT, o, lane, res);
     }
 }
 
 // g_in = (W^T g_out) * elu'(x_in): OUT_T gradient tiles -> IN_T gradient tiles (x_in = stored post-activation of the layer input)
 // (KEEP_B: also keep the MFMA B-operand form of the result -- not needed for the first hidden layer, whose input gets no gradient)
 template <int IN_T, int OUT_T, bool KEEP_B>
-LG_DEV void train_backward_layer(const float *__restrict__ W, int in_dim, int out_dim, const float4 (*gout)[64], const float4 (*xin)[64],
+LG_DEV void train_backward_layer(const float *wl, const float4 (*gout)[64], const float4 (*xin)[64],
                                  float4 (*gin)[64], float (*ginT)[16][LG_TT], int wave, int lane) {
+    using L = LdsLayer<IN_T, OUT_T>;
     const int g = lane >> 4;
 #pragma unroll 1
     for (int ti = wave; ti < IN_T; ti += LG_TRAIN_WAVES) {
-        const float *wc = W + 16 * ti + (lane & 15);             // column of W = row of W^T; hidden widths are multiples of 16
+        const float *wc = wl + 4 * g * L::stride + 16 * ti + (lane & 15);      // column of W = row of W^T
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int o = 0; o < OUT_T; o++) {
-            float a[4];
-#pragma unroll
-            for (int r = 0; r < 4; r++) { const int k = 16 * o + 4 * g + r; a[r] = k < out_dim ? wc[(size_t)k * in_dim] : 0.0f; }
             const float4 gv = gout[o][lane];
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], gv.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], gv.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], gv.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], gv.w, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[(16 * o + 0) * L::stride], gv.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[(16 * o + 1) * L::stride], gv.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[(16 * o + 2) * L::stride], gv.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[(16 * o + 3) * L::stride], gv.w, acc, 0, 0, 0);
         }
         const float4 xv = xin[ti][lane];
         const float4 res = make_float4(acc[0] * (xv.x > 0.f ? 1.f : xv.x + 1.f), acc[1] * (xv.y > 0.f ? 1.f : xv.y + 1.f),
                                        acc[2] * (xv.z > 0.f ? 1.f : xv.z + 1.f), acc[3] * (xv.w > 0.f ? 1.f : xv.w + 1.f));
         if (KEEP_B) gin[ti][lane] = res;
-        const int r = lane & 15;
-        ginT[ti][4 * g + 0][r] = res.x; ginT[ti][4 * g + 1][r] = res.y; ginT[ti][4 * g + 2][r] = res.z; ginT[ti][4 * g + 3][r] = res.w;
+        tile_store_t(ginT, ti, lane, res);
     }
 }
 
@@ -126,15 +148,13 @@ LG_DEV void train_weight_grad(const float (*gT)[16][LG_TT], const float (*xT)[16
         const int p = wave + LG_TRAIN_WAVES * i;
         if (p < PC::total) {
             const int o = p / (IN_T + 1), t = p % (IN_T + 1);
-            const float *ga = &gT[o][f][r0];
-            if (t < IN_T) {
-                const float *xb = &xT[t][f][r0];
-#pragma unroll
-                for (int s = 0; s < 4; s++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s], xb[s], acc[i], 0, 0, 0);
-            } else {
-#pragma unroll
-                for (int s = 0; s < 4; s++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s], 1.0f, acc[i], 0, 0, 0);
-            }
+            const float4 ga = *reinterpret_cast<const float4 *>(&gT[o][f][r0]);
+            float4 xb = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (t < IN_T) xb = *reinterpret_cast<const float4 *>(&xT[t][f][r0]);
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga.x, xb.x, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga.y, xb.y, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga.z, xb.z, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga.w, xb.w, acc[i], 0, 0, 0);
         }
     }
 }
@@ -163,20 +183,35 @@ LG_DEV void train_flush(const f32x4 *acc, float *__restrict__ part, int in_dim, 
     }
 }
 
-// One workgroup walks row tiles blockIdx.x, blockIdx.x + gridDim.x, ... of net blockIdx.y.
+// LDS budget of k_mlp_train in floats (dynamic shared memory; the backward build needs ~138 KB of the CU's 160 KB)
+template <int D0T, int D1T, int D2T, int D3T, bool BWD> struct TrainLds {
+    static constexpr int XT = D0T + D1T + D2T + D3T, GT = D1T + D2T + D3T + 1, BT = D2T + D3T + 1;
+    static constexpr int w0 = 0, w1 = w0 + LdsLayer<D0T, D1T>::floats, w2 = w1 + LdsLayer<D1T, D2T>::floats, w3 = w2 + LdsLayer<D2T, D3T>::floats,
+                         x = w3 + LdsLayer<D3T, 1>::floats, xT = x + XT * 256, gr = xT + (BWD ? XT * 16 * LG_TT : 0),
+                         gT = gr + (BWD ? BT * 256 : 0), floats = gT + (BWD ? GT * 16 * LG_TT : 0);
+};
+
+// One persistent workgroup per (slice blockIdx.x, net blockIdx.y): weights -> LDS once, then row tiles blockIdx.x, + gridDim.x, ...
 template <int D0T, int D1T, int D2T, int D3T, bool BWD>
 __global__ void __launch_bounds__(64 * LG_TRAIN_WAVES) k_mlp_train(const MlpArgs A) {
-    constexpr int XT = D0T + D1T + D2T + D3T, GT = D1T + D2T + D3T + 1;
+    using S = TrainLds<D0T, D1T, D2T, D3T, BWD>;
     constexpr int X0 = 0, X1 = D0T, X2 = D0T + D1T, X3 = D0T + D1T + D2T;        // activation tile offsets
     constexpr int G1 = 0, G2 = D1T, G3 = D1T + D2T, G4 = D1T + D2T + D3T;        // gradient tiles w.r.t. x1, x2, x3 pre-acts, and y
-    constexpr int B2 = 0, B3 = D2T, B4 = D2T + D3T, BT = D2T + D3T + 1;          // B-operand copies exist for g2, g3, dy only
-    __shared__ float4 x[XT][64];
-    __shared__ float  xT[BWD ? XT : 1][16][LG_TT];
-    __shared__ float4 gr[BWD ? BT : 1][64];
-    __shared__ float  gT[BWD ? GT : 1][16][LG_TT];
+    constexpr int B2 = 0, B3 = D2T, B4 = D2T + D3T;                              // B-operand copies exist for g2, g3, dy only
+    extern __shared__ float4 lds_raw[];
+    float *lds = reinterpret_cast<float *>(lds_raw);
+    float *wl0 = lds + S::w0, *wl1 = lds + S::w1, *wl2 = lds + S::w2, *wl3 = lds + S::w3;
+    float4 (*x)[64] = reinterpret_cast<float4 (*)[64]>(lds + S::x);
+    float (*xT)[16][LG_TT] = reinterpret_cast<float (*)[16][LG_TT]>(lds + S::xT);
+    float4 (*gr)[64] = reinterpret_cast<float4 (*)[64]>(lds + S::gr);
+    float (*gT)[16][LG_TT] = reinterpret_cast<float (*)[16][LG_TT]>(lds + S::gT);
     const MlpNetArgs &N = A.net[blockIdx.y];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4;
     const int d0 = N.dims[0], d1 = N.dims[1], d2 = N.dims[2], d3 = N.dims[3], d4 = N.dims[4];
+    lds_layer_fill<D0T, D1T>(wl0, N.w[0], N.b[0], d0, d1, threadIdx.x);
+    lds_layer_fill<D1T, D2T>(wl1, N.w[1], N.b[1], d1, d2, threadIdx.x);
+    lds_layer_fill<D2T, D3T>(wl2, N.w[2], N.b[2], d2, d3, threadIdx.x);
+    lds_layer_fill<D3T, 1>(wl3, N.w[3], N.b[3], d3, d4, threadIdx.x);
     using P0 = PairCount<D0T, D1T>; using P1 = PairCount<D1T, D2T>; using P2 = PairCount<D2T, D3T>; using P3 = PairCount<D3T, 1>;
     f32x4 a0[BWD ? P0::per_wave : 1], a1[BWD ? P1::per_wave : 1], a2[BWD ? P2::per_wave : 1], a3[BWD ? P3::per_wave : 1];
     if (BWD) {
@@ -189,36 +224,51 @@ __global__ void __launch_bounds__(64 * LG_TRAIN_WAVES) k_mlp_train(const MlpArgs
 #pragma unroll
         for (int i = 0; i < P3::per_wave; i++) a3[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-#pragma unroll 1
-    for (int rt = blockIdx.x; rt < A.n_tiles; rt += gridDim.x) {
+    // The inputs of row tile rt + gridDim.x are requested while tile rt is computed: a lone wave per SIMD has nothing else
+    // to hide the gather's two dependent global loads (row index, then the row) behind.
+    static_assert(D0T <= LG_TRAIN_WAVES, "one input tile per wave");
+    float4 xv_next = make_float4(0.f, 0.f, 0.f, 0.f), dy_next = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto request = [&](int rt) {
         const int r = rt * 16 + (lane & 15);
         const bool live = r < A.mb;
-        const int64_t src = live ? (A.rows ? A.rows[r] : (int64_t)r) : (A.rows ? A.rows[A.mb - 1] : (int64_t)(A.mb - 1));
-        const float *xr = N.x + (size_t)src * d0;
-        for (int t = wave; t < D0T; t += LG_TRAIN_WAVES) {
+        if (wave < D0T) {
+            const int64_t src = live ? (A.rows ? A.rows[r] : (int64_t)r) : (A.rows ? A.rows[A.mb - 1] : (int64_t)(A.mb - 1));
+            const float *xr = N.x + (size_t)src * d0;
             float v[4];
 #pragma unroll
-            for (int c = 0; c < 4; c++) { const int k = 16 * t + 4 * g + c; v[c] = k < d0 ? xr[k] : 0.0f; }
-            const float4 xv = make_float4(v[0], v[1], v[2], v[3]);
-            if (BWD) tile_store(x + X0, xT + X0, t, lane, xv); else x[X0 + t][lane] = xv;
+            for (int c = 0; c < 4; c++) { const int k = 16 * wave + 4 * g + c; v[c] = k < d0 ? xr[k] : 0.0f; }
+            xv_next = make_float4(v[0], v[1], v[2], v[3]);
         }
-        __syncthreads();
-        train_forward_layer<D0T, D1T, true, true, BWD>(N.w[0], N.b[0], d0, d1, x + X0, x + X1, xT + (BWD ? X1 : 0), wave, lane);
-        __syncthreads();
-        train_forward_layer<D1T, D2T, true, false, BWD>(N.w[1], N.b[1], d1, d2, x + X1, x + X2, xT + (BWD ? X2 : 0), wave, lane);
-        __syncthreads();
-        train_forward_layer<D2T, D3T, true, false, BWD>(N.w[2], N.b[2], d2, d3, x + X2, x + X3, xT + (BWD ? X3 : 0), wave, lane);
         if (BWD && wave == LG_TRAIN_WAVES - 1) {                   // dL/dy tile (zero for rows past the batch: they contribute nothing)
             float v[4];
 #pragma unroll
             for (int c = 0; c < 4; c++) { const int k = 4 * g + c; v[c] = (live && k < d4) ? N.dy[(size_t)r * d4 + k] : 0.0f; }
-            tile_store(gr + B4, gT + G4, 0, lane, make_float4(v[0], v[1], v[2], v[3]));
+            dy_next = make_float4(v[0], v[1], v[2], v[3]);
         }
+    };
+    request(blockIdx.x);
+#pragma unroll 1
+    for (int rt = blockIdx.x; rt < A.n_tiles; rt += gridDim.x) {
+        const int r = rt * 16 + (lane & 15);
+        const bool live = r < A.mb;
+        const float4 dyv = dy_next;
+        if (wave < D0T) {
+            x[X0 + wave][lane] = xv_next;
+            if (BWD) tile_store_t(xT + X0, wave, lane, xv_next);
+        }
+        if (rt + (int)gridDim.x < A.n_tiles) request(rt + gridDim.x);
+        __syncthreads();                                           // (first pass: also the weights are in LDS)
+        train_forward_layer<D0T, D1T, true, BWD>(wl0, x + X0, x + X1, xT + (BWD ? X1 : 0), wave, lane);
+        __syncthreads();
+        train_forward_layer<D1T, D2T, true, BWD>(wl1, x + X1, x + X2, xT + (BWD ? X2 : 0), wave, lane);
+        __syncthreads();
+        train_forward_layer<D2T, D3T, true, BWD>(wl2, x + X2, x + X3, xT + (BWD ? X3 : 0), wave, lane);
+        if (BWD && wave == LG_TRAIN_WAVES - 1) { gr[B4][lane] = dyv; tile_store_t(gT + G4, 0, lane, dyv); }
         __syncthreads();
         if (!BWD) {
             if (wave == 0) {
                 // the output layer reuses x tile X0 as scratch (its inputs are no longer needed in forward-only mode)
-                train_forward_layer<D3T, 1, false, false, false>(N.w[3], N.b[3], d3, d4, x + X3, x + X0, nullptr, 0, lane);
+                train_forward_layer<D3T, 1, false, false>(wl3, x + X3, x + X0, nullptr, 0, lane);
                 const float4 yv = x[X0][lane];
                 const float y4[4] = {yv.x, yv.y, yv.z, yv.w};
 #pragma unroll
@@ -228,13 +278,13 @@ __global__ void __launch_bounds__(64 * LG_TRAIN_WAVES) k_mlp_train(const MlpArgs
             continue;
         }
         // output layer: dW3 / db3 and g3 = (W3^T dy) * elu'(x3)
-        train_backward_layer<D3T, 1, true>(N.w[3], d3, d4, gr + B4, x + X3, gr + B3, gT + G3, wave, lane);
+        train_backward_layer<D3T, 1, true>(wl3, gr + B4, x + X3, gr + B3, gT + G3, wave, lane);
         train_weight_grad<D3T, 1>(gT + G4, xT + X3, a3, wave, lane);
         __syncthreads();
-        train_backward_layer<D2T, D3T, true>(N.w[2], d2, d3, gr + B3, x + X2, gr + B2, gT + G2, wave, lane);
+        train_backward_layer<D2T, D3T, true>(wl2, gr + B3, x + X2, gr + B2, gT + G2, wave, lane);
         train_weight_grad<D2T, D3T>(gT + G3, xT + X2, a2, wave, lane);
         __syncthreads();
-        train_backward_layer<D1T, D2T, false>(N.w[1], d1, d2, gr + B2, x + X1, nullptr, gT + G1, wave, lane);
+        train_backward_layer<D1T, D2T, false>(wl1, gr + B2, x + X1, nullptr, gT + G1, wave, lane);
         train_weight_grad<D1T, D2T>(gT + G2, xT + X1, a1, wave, lane);
         __syncthreads();
         train_weight_grad<D0T, D1T>(gT + G1, xT + X0, a0, wave, lane);
@@ -280,6 +330,60 @@ __global__ void __launch_bounds__(256) k_mlp_reduce(const MlpReduceArgs A) {
         if (off < nb) { A.gb[n][l][off] = s; return; }
         off -= nb;
     }
+}
+
+// ---- gradient-norm clip + Adam + adaptive-KL learning rate: the rest of a PPO mini-batch step in two launches ---------------
+#define LG_ADAM_MAX_TENSORS 32
+struct AdamTensor { float *param; const float *grad; float *exp_avg, *exp_avg_sq, *step; int64_t numel; };
+struct AdamArgs {
+    AdamTensor t[LG_ADAM_MAX_TENSORS];
+    int32_t n_tensors;
+    float *lr;                 // device scalar (read by the update, written by the KL rule)
+    const float *kl;           // device scalar or null (fixed schedule)
+    float *scratch;            // [2]: total gradient norm, clip coefficient
+    float beta1, beta2, eps, max_norm, desired_kl;
+};
+
+// one workgroup: ||g||_2 over all tensors in a fixed order -> clip coefficient; step counters += 1; the KL rule on lr
+// (rsl_rl PPO.update [EXTERNAL]: kl > 2 d -> lr = max(1e-5, lr / 1.5); 0 < kl < d / 2 -> lr = min(1e-2, lr * 1.5))
+__global__ void __launch_bounds__(1024) k_adam_prepare(const AdamArgs A) {
+    __shared__ float red[1024];
+    float s = 0.0f;
+    for (int k = 0; k < A.n_tensors; k++) {
+        const float *g = A.t[k].grad;
+        for (int64_t i = threadIdx.x; i < A.t[k].numel; i += 1024) s = fmaf(g[i], g[i], s);
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if ((int)threadIdx.x < A.n_tensors) A.t[threadIdx.x].step[0] += 1.0f;
+    if (threadIdx.x == 0) {
+        const float norm = sqrtf(red[0]);
+        A.scratch[0] = norm;
+        A.scratch[1] = fminf(1.0f, A.max_norm / (norm + 1e-6f));      // torch.nn.utils.clip_grad_norm_
+        if (A.kl && A.desired_kl > 0.0f) {
+            const float kl = A.kl[0], lr = A.lr[0];
+            if (kl > 2.0f * A.desired_kl) A.lr[0] = fmaxf(1e-5f, lr / 1.5f);
+            else if (kl < 0.5f * A.desired_kl && kl > 0.0f) A.lr[0] = fminf(1e-2f, lr * 1.5f);
+        }
+    }
+}
+
+// torch.optim.Adam (no weight decay, no amsgrad) on the clipped gradient; tensor blockIdx.y, 256 elements per workgroup
+__global__ void __launch_bounds__(256) k_adam_update(const AdamArgs A) {
+    const AdamTensor &T = A.t[blockIdx.y];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= T.numel) return;
+    const float step = T.step[0], lr = A.lr[0], coef = A.scratch[1];
+    const float bc1 = 1.0f - powf(A.beta1, step), bc2 = 1.0f - powf(A.beta2, step);
+    const float g = T.grad[i] * coef;
+    const float m = T.exp_avg[i] + (g - T.exp_avg[i]) * (1.0f - A.beta1);
+    const float v = T.exp_avg_sq[i] * A.beta2 + (1.0f - A.beta2) * g * g;
+    T.exp_avg[i] = m; T.exp_avg_sq[i] = v;
+    T.param[i] -= (lr / bc1) * m / (sqrtf(v) / sqrtf(bc2) + A.eps);
 }
 
 }  // namespace lg

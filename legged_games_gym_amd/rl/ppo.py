@@ -140,6 +140,9 @@ class PPO:
         # (lg_mlp_forward / lg_mlp_backward, rl/mlp_kernels.py): autograd is not involved at all.  LG_PPO_MLP_KERNELS=0 disables.
         self._mlp_kernels = self._fused_loss and _os.environ.get("LG_PPO_MLP_KERNELS", "1") != "0"
         self._mlp = None
+        # ... and gradient clipping, the adaptive-KL learning-rate rule and Adam are two launches (lg_adam_step) instead of ~60
+        # small torch kernels, updating torch.optim.Adam's own state tensors in place.  LG_PPO_ADAM_KERNEL=0 disables.
+        self._adam_kernel = self._fused_loss and _os.environ.get("LG_PPO_ADAM_KERNEL", "1") != "0"
         self._lib = None
         self.desired_kl, self.schedule, self.learning_rate = desired_kl, schedule, learning_rate
         self.actor_critic = actor_critic.to(device)
@@ -255,6 +258,32 @@ class PPO:
                 return None
         return self._mlp
 
+    def _adam_table(self):
+        """lg_adam_tensor[] over torch.optim.Adam's parameters and state, or None while the state does not exist yet (the very
+        first step is torch's: it creates exp_avg / exp_avg_sq / step) or the optimiser is not plain capturable Adam."""
+        from .. import capi
+        opt = self.optimizer
+        if len(opt.param_groups) != 1:
+            return None
+        g = opt.param_groups[0]
+        if g.get("amsgrad") or g.get("weight_decay") or g.get("maximize") or not g.get("capturable") or g["lr"] is not self._lr:
+            return None
+        params = [q for q in g["params"] if q.grad is not None]
+        if not params or len(params) > 32:
+            return None
+        table = (capi.lg_adam_tensor * len(params))()
+        for i, q in enumerate(params):
+            stt = opt.state.get(q)
+            if not stt or "exp_avg" not in stt or not torch.is_tensor(stt["step"]) or stt["step"].dtype != torch.float32 \
+                    or not stt["step"].is_cuda or q.dtype != torch.float32 or not q.is_contiguous() or not q.grad.is_contiguous():
+                return None
+            t = table[i]
+            t.param, t.grad, t.exp_avg, t.exp_avg_sq = q.data_ptr(), q.grad.data_ptr(), stt["exp_avg"].data_ptr(), stt["exp_avg_sq"].data_ptr()
+            t.step, t.numel = stt["step"].data_ptr(), q.numel()
+        if getattr(self, "_adam_scratch", None) is None:
+            self._adam_scratch = torch.zeros(2, device=self.device)
+        return table
+
     def _mb_step_fused(self):
         """Mini-batch step with the fused loss kernel: MLP forward -> lg_ppo_loss -> MLP backward -> clip -> Adam.  The MLP
         passes are the MFMA learner kernels when the networks have their shape, torch (autograd) otherwise."""
@@ -281,18 +310,29 @@ class PPO:
                                    torch.cuda.current_stream(mu.device).cuda_stream)
         if rc != 0:
             raise RuntimeError(f"lg_ppo_loss failed ({rc}): {self._lib.lg_last_error().decode()}")
-        if self.desired_kl is not None and self.schedule == "adaptive":
-            with torch.no_grad():
-                kl, lr = self._stats[2], self._lr
-                down, up = torch.clamp(lr / 1.5, min=1e-5), torch.clamp(lr * 1.5, max=1e-2)
-                self._lr.copy_(torch.where(kl > self.desired_kl * 2.0, down, torch.where((kl < self.desired_kl / 2.0) & (kl > 0.0), up, lr)))
         if tr is not None:
             tr.backward(ix)
         else:
             torch.autograd.backward([mu, val], [d_mu, d_val])
         ac.std.grad = self._d_std
-        nn.utils.clip_grad_norm_(ac.parameters(), self.max_grad_norm)
-        self.optimizer.step()
+        adaptive = self.desired_kl is not None and self.schedule == "adaptive"
+        table = self._adam_table() if self._adam_kernel else None
+        if table is not None:
+            g = self.optimizer.param_groups[0]
+            rc = self._lib.lg_adam_step(table, len(table), p(self._lr), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
+                                        float(self.max_grad_norm), p(self._stats[2:]) if adaptive else None,
+                                        float(self.desired_kl) if adaptive else 0.0, p(self._adam_scratch),
+                                        torch.cuda.current_stream(mu.device).cuda_stream)
+            if rc != 0:
+                raise RuntimeError(f"lg_adam_step failed ({rc}): {self._lib.lg_last_error().decode()}")
+        else:
+            if adaptive:
+                with torch.no_grad():
+                    kl, lr = self._stats[2], self._lr
+                    down, up = torch.clamp(lr / 1.5, min=1e-5), torch.clamp(lr * 1.5, max=1e-2)
+                    self._lr.copy_(torch.where(kl > self.desired_kl * 2.0, down, torch.where((kl < self.desired_kl / 2.0) & (kl > 0.0), up, lr)))
+            nn.utils.clip_grad_norm_(ac.parameters(), self.max_grad_norm)
+            self.optimizer.step()
         with torch.no_grad():
             self._acc[0] += self._stats[1]
             self._acc[1] += self._stats[0]

@@ -142,3 +142,44 @@ def test_mlp_kernels_match_autograd(mb, gather):
     first = [h.clone() for h in got]
     tr.backward(rows)
     assert all(torch.equal(a, b) for a, b in zip(first, got))
+
+
+def test_adam_kernel_matches_torch_adam_with_clipping():
+    """lg_adam_step against clip_grad_norm_ + torch.optim.Adam(capturable=True).step() on the optimiser's own state tensors."""
+    import torch.nn as nn
+    from legged_games_gym_amd import capi
+    lib = capi.load_library()
+    nets = [_mlp(48, 12, 3), _mlp(48, 12, 3)]
+    lrs = [torch.tensor(1e-3, device="cuda"), torch.tensor(1e-3, device="cuda")]
+    opts = [torch.optim.Adam(n.parameters(), lr=l, capturable=True) for n, l in zip(nets, lrs)]
+    g = torch.Generator(device="cuda").manual_seed(9)
+    scratch = torch.zeros(2, device="cuda")
+    for it in range(6):
+        grads = [torch.randn(q.shape, device="cuda", generator=g) * (3.0 if it % 2 else 0.01) for q in nets[0].parameters()]
+        for n in nets:
+            for q, gr in zip(n.parameters(), grads):
+                q.grad = gr.clone()
+        kl = torch.tensor([0.05, 0.001, 0.01][it % 3], device="cuda")
+        # torch side (reference order: KL rule, clip, step)
+        lr = lrs[0]
+        lr.copy_(torch.where(kl > 0.02, torch.clamp(lr / 1.5, min=1e-5), torch.where((kl < 0.005) & (kl > 0), torch.clamp(lr * 1.5, max=1e-2), lr)))
+        nn.utils.clip_grad_norm_(nets[0].parameters(), 1.0)
+        opts[0].step()
+        if it == 0:                       # the first step creates the optimiser state: torch's on both sides
+            lrs[1].copy_(lr); nn.utils.clip_grad_norm_(nets[1].parameters(), 1.0); opts[1].step()
+            continue
+        params = list(nets[1].parameters())
+        table = (capi.lg_adam_tensor * len(params))()
+        for i, q in enumerate(params):
+            stt = opts[1].state[q]
+            table[i].param, table[i].grad, table[i].exp_avg, table[i].exp_avg_sq = q.data_ptr(), q.grad.data_ptr(), stt["exp_avg"].data_ptr(), stt["exp_avg_sq"].data_ptr()
+            table[i].step, table[i].numel = stt["step"].data_ptr(), q.numel()
+        rc = lib.lg_adam_step(table, len(params), lrs[1].data_ptr(), 0.9, 0.999, 1e-8, 1.0, kl.data_ptr(), 0.01, scratch.data_ptr(),
+                              torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, lib.lg_last_error()
+        assert abs(float(lrs[0]) - float(lrs[1])) < 1e-9
+        for a, b in zip(nets[0].parameters(), nets[1].parameters()):
+            assert float((a - b).abs().max()) < 2e-6, it
+        for a, b in zip(nets[0].parameters(), nets[1].parameters()):
+            assert float((opts[0].state[a]["exp_avg_sq"] - opts[1].state[b]["exp_avg_sq"]).abs().max()) < 1e-6
+            assert float(opts[0].state[a]["step"]) == float(opts[1].state[b]["step"])

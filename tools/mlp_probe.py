@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Times the learner kernels (lg_mlp_forward / lg_mlp_backward) against torch autograd on the flat actor+critic shapes."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.realpath(__file__))))
+import torch, torch.nn as nn
+from legged_games_gym_amd.rl.mlp_kernels import MlpTrainer
+
+def mlp(i, o):
+    return nn.Sequential(nn.Linear(i, 128), nn.ELU(), nn.Linear(128, 64), nn.ELU(), nn.Linear(64, 32), nn.ELU(), nn.Linear(32, o)).cuda()
+
+mb, R = int(os.environ.get("MB", 24576)), 98304
+actor, critic = mlp(48, 12), mlp(48, 1)
+x = torch.randn(R, 48, device="cuda")
+rows = torch.randperm(R, device="cuda")[:mb]
+tr = MlpTrainer([actor, critic], [x, x], mb)
+assert tr.supported
+
+def timeit(fn, n=200):
+    for _ in range(20): fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / n * 1e3
+
+def torch_step():
+    xb = x[rows]
+    mu, v = actor(xb), critic(xb)
+    torch.autograd.backward([mu, v], [tr.grad_outputs[0], tr.grad_outputs[1]])
+
+flops_fwd = 2 * mb * sum(a * b for net in (actor, critic) for a, b in [(m.in_features, m.out_features) for m in net if isinstance(m, nn.Linear)])
+tf, tb, tt = timeit(lambda: tr.forward(rows)), timeit(lambda: tr.backward(rows)), timeit(torch_step, 50)
+print(f"mb {mb}: lg_mlp_forward {tf:.1f} us ({flops_fwd / tf / 1e6:.1f} TFLOP/s)  lg_mlp_backward(+recompute, reduce) {tb:.1f} us "
+      f"({3 * flops_fwd / tb / 1e6:.1f} TFLOP/s)  torch fwd+bwd {tt:.1f} us")
