@@ -1466,10 +1466,13 @@ __global__ void k_policy_pack(const float *__restrict__ W, const float *__restri
 
 // ---- PPO learner: MLP forward / backward for up to two nets (actor, critic) in one launch -------------------------------------
 #define LG_TRAIN_WGS 256           /* workgroups per net = partial-sum slices */
-static int mlp_fill(const lg_mlp_net *nets, int32_t n_nets, const int64_t *rows, int32_t mb, lg::MlpArgs &a, int &wgs) {
+static unsigned long long *g_mlp_trace = nullptr;   /* diagnostic, see lg_mlp_trace */
+#define LG_FWD_SLOTS 4             /* row tiles in flight per workgroup (forward: 140 KB of LDS) */
+#define LG_BWD_SLOTS 1             /* backward: 138 KB with one */
+static int mlp_fill(const lg_mlp_net *nets, int32_t n_nets, const int64_t *rows, int32_t mb, lg::MlpArgs &a, int &wgs, int slots, bool partials) {
     if (!nets || n_nets < 1 || n_nets > 2 || mb <= 0) return fail(-1, "bad argument");
     memset(&a, 0, sizeof a);
-    a.rows = rows; a.mb = mb; a.n_tiles = (mb + 15) / 16;
+    a.rows = rows; a.mb = mb; a.n_tiles = (mb + 15) / 16; a.trace = g_mlp_trace;
     // persistent workgroups, one per CU (the LDS-resident weights allow no more): the CUs are split between the nets
     static int num_cus = 0;
     if (!num_cus) {
@@ -1478,8 +1481,8 @@ static int mlp_fill(const lg_mlp_net *nets, int32_t n_nets, const int64_t *rows,
             num_cus = 256;
     }
     wgs = num_cus / n_nets;
-    if (wgs > LG_TRAIN_WGS) wgs = LG_TRAIN_WGS;
-    if (wgs > a.n_tiles) wgs = a.n_tiles;
+    if (partials && wgs * slots > LG_TRAIN_WGS) wgs = LG_TRAIN_WGS / slots;       // backward: one partial-sum slice per group
+    if (wgs * slots > a.n_tiles) wgs = (a.n_tiles + slots - 1) / slots;
     if (wgs < 1) wgs = 1;
     for (int n = 0; n < n_nets; n++) {
         const lg_mlp_net &s = nets[n];
@@ -1502,17 +1505,20 @@ static int mlp_fill(const lg_mlp_net *nets, int32_t n_nets, const int64_t *rows,
 
 extern "C" {
 
+/* diagnostic (tools/mlp_probe.py): later lg_mlp_* launches write up to 60 s_memtime stamps of workgroup (0,0) to `buf` (device, u64[60]); null stops */
+void lg_mlp_trace(unsigned long long *buf) { g_mlp_trace = buf; }
+
 int lg_mlp_forward(const lg_mlp_net *nets, int32_t n_nets, const int64_t *rows, int32_t mb, void *stream) {
     lg::MlpArgs a; int wgs;
-    if (int rc = mlp_fill(nets, n_nets, rows, mb, a, wgs)) return rc;
+    if (int rc = mlp_fill(nets, n_nets, rows, mb, a, wgs, LG_FWD_SLOTS, false)) return rc;
     for (int n = 0; n < n_nets; n++) if (!nets[n].output) return fail(-1, "null output");
-    constexpr size_t lds_bytes = lg::TrainLds<3, 8, 4, 2, false>::floats * sizeof(float);
+    constexpr size_t lds_bytes = lg::TrainLds<3, 8, 4, 2, false, LG_FWD_SLOTS>::floats * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void *)lg::k_mlp_train<3, 8, 4, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        HIP_TRY(hipFuncSetAttribute((const void *)lg::k_mlp_train<3, 8, 4, 2, false, LG_FWD_SLOTS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         attr_set = true;
     }
-    hipLaunchKernelGGL((lg::k_mlp_train<3, 8, 4, 2, false>), dim3(wgs, n_nets), dim3(64 * LG_TRAIN_WAVES), lds_bytes, (hipStream_t)stream, a);
+    hipLaunchKernelGGL((lg::k_mlp_train<3, 8, 4, 2, false, LG_FWD_SLOTS>), dim3(wgs, n_nets), dim3(64 * LG_TRAIN_WAVES * LG_FWD_SLOTS), lds_bytes, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1531,7 +1537,7 @@ size_t lg_mlp_workspace_bytes(const lg_mlp_net *nets, int32_t n_nets) {
 int lg_mlp_backward(const lg_mlp_net *nets, int32_t n_nets, const int64_t *rows, int32_t mb, float *workspace, size_t workspace_bytes,
                     void *stream) {
     lg::MlpArgs a; int wgs;
-    if (int rc = mlp_fill(nets, n_nets, rows, mb, a, wgs)) return rc;
+    if (int rc = mlp_fill(nets, n_nets, rows, mb, a, wgs, LG_BWD_SLOTS, true)) return rc;
     if (!workspace || workspace_bytes < lg_mlp_workspace_bytes(nets, n_nets)) return fail(-1, "workspace too small (lg_mlp_workspace_bytes)");
     lg::MlpReduceArgs r; memset(&r, 0, sizeof r);
     float *ws = workspace;
@@ -1546,17 +1552,17 @@ int lg_mlp_backward(const lg_mlp_net *nets, int32_t n_nets, const int64_t *rows,
             r.gw[n][l] = nets[n].grad_weights[l]; r.gb[n][l] = nets[n].grad_biases[l];
         }
     }
-    r.n_partials = wgs;
+    r.n_partials = wgs * LG_BWD_SLOTS;
     hipStream_t st = (hipStream_t)stream;
-    constexpr size_t lds_bytes = lg::TrainLds<3, 8, 4, 2, true>::floats * sizeof(float);
+    constexpr size_t lds_bytes = lg::TrainLds<3, 8, 4, 2, true, LG_BWD_SLOTS>::floats * sizeof(float);
     static_assert(lds_bytes <= 160 * 1024, "k_mlp_train backward exceeds the CU's LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void *)lg::k_mlp_train<3, 8, 4, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        HIP_TRY(hipFuncSetAttribute((const void *)lg::k_mlp_train<3, 8, 4, 2, true, LG_BWD_SLOTS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         attr_set = true;
     }
-    hipLaunchKernelGGL((lg::k_mlp_train<3, 8, 4, 2, true>), dim3(wgs, n_nets), dim3(64 * LG_TRAIN_WAVES), lds_bytes, st, a);
-    hipLaunchKernelGGL(lg::k_mlp_reduce, dim3((max_gf + 255) / 256, n_nets), dim3(256), 0, st, r);
+    hipLaunchKernelGGL((lg::k_mlp_train<3, 8, 4, 2, true, LG_BWD_SLOTS>), dim3(wgs, n_nets), dim3(64 * LG_TRAIN_WAVES * LG_BWD_SLOTS), lds_bytes, st, a);
+    hipLaunchKernelGGL(lg::k_mlp_reduce, dim3((max_gf + 31) / 32, n_nets), dim3(256), 0, st, r);
     HIP_TRY(hipGetLastError());
     return 0;
 }

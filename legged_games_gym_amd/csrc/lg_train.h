@@ -38,6 +38,7 @@ struct MlpArgs {
     MlpNetArgs net[2];
     const int64_t *rows;               // [mb] row indices into x, or null for 0..mb-1
     int32_t mb, n_tiles;
+    unsigned long long *trace;         // diagnostic: s_memtime stamps of workgroup (0, 0), thread 0 (lg_mlp_trace); null in normal use
 };
 
 // LDS image of one Linear layer: rows 16*OUT_T (zero beyond out_dim), IN_T*16 columns (zero beyond in_dim) + LG_WPAD, then the bias
@@ -45,9 +46,9 @@ template <int IN_T, int OUT_T> struct LdsLayer {
     static constexpr int stride = 16 * IN_T + LG_WPAD, w_floats = 16 * OUT_T * stride, floats = w_floats + 16 * OUT_T;
 };
 template <int IN_T, int OUT_T>
-LG_DEV void lds_layer_fill(float *wl, const float *__restrict__ W, const float *__restrict__ b, int in_dim, int out_dim, int tid) {
+LG_DEV void lds_layer_fill(float *wl, const float *__restrict__ W, const float *__restrict__ b, int in_dim, int out_dim, int tid, int NT) {
     using L = LdsLayer<IN_T, OUT_T>;
-    constexpr int QPR = 4 * IN_T, NQ = 16 * OUT_T * QPR, NT = 64 * LG_TRAIN_WAVES;     // quads per row / in the layer
+    constexpr int QPR = 4 * IN_T, NQ = 16 * OUT_T * QPR;                                // quads per row / in the layer
     const bool vec = (in_dim & 3) == 0;
     // batches of 4 quads per thread: all the loads of a batch are in flight before the first LDS store needs one
 #pragma unroll 1
@@ -184,34 +185,40 @@ LG_DEV void train_flush(const f32x4 *acc, float *__restrict__ part, int in_dim, 
 }
 
 // LDS budget of k_mlp_train in floats (dynamic shared memory; the backward build needs ~138 KB of the CU's 160 KB)
-template <int D0T, int D1T, int D2T, int D3T, bool BWD> struct TrainLds {
+template <int D0T, int D1T, int D2T, int D3T, bool BWD, int SLOTS> struct TrainLds {
     static constexpr int XT = D0T + D1T + D2T + D3T, GT = D1T + D2T + D3T + 1, BT = D2T + D3T + 1;
     static constexpr int w0 = 0, w1 = w0 + LdsLayer<D0T, D1T>::floats, w2 = w1 + LdsLayer<D1T, D2T>::floats, w3 = w2 + LdsLayer<D2T, D3T>::floats,
-                         x = w3 + LdsLayer<D3T, 1>::floats, xT = x + XT * 256, gr = xT + (BWD ? XT * 16 * LG_TT : 0),
-                         gT = gr + (BWD ? BT * 256 : 0), floats = gT + (BWD ? GT * 16 * LG_TT : 0);
+                         slots = w3 + LdsLayer<D3T, 1>::floats;                  // weights, then SLOTS row-tile work areas:
+    static constexpr int x = 0, xT = x + XT * 256, gr = xT + (BWD ? XT * 16 * LG_TT : 0), gT = gr + (BWD ? BT * 256 : 0),
+                         slot_floats = gT + (BWD ? GT * 16 * LG_TT : 0), floats = slots + SLOTS * slot_floats;
 };
 
-// One persistent workgroup per (slice blockIdx.x, net blockIdx.y): weights -> LDS once, then row tiles blockIdx.x, + gridDim.x, ...
-template <int D0T, int D1T, int D2T, int D3T, bool BWD>
-__global__ void __launch_bounds__(64 * LG_TRAIN_WAVES) k_mlp_train(const MlpArgs A) {
-    using S = TrainLds<D0T, D1T, D2T, D3T, BWD>;
+// One persistent workgroup per (slice blockIdx.x, net blockIdx.y): weights -> LDS once, then it walks its row tiles.  SLOTS
+// groups of LG_TRAIN_WAVES waves each work on their own row tile (own activation area, shared weights): with several waves
+// per SIMD one group's MFMAs overlap another's LDS traffic and ELUs.  All groups run the same barrier sequence.
+template <int D0T, int D1T, int D2T, int D3T, bool BWD, int SLOTS>
+__global__ void __launch_bounds__(64 * LG_TRAIN_WAVES * SLOTS) k_mlp_train(const MlpArgs A) {
+    using S = TrainLds<D0T, D1T, D2T, D3T, BWD, SLOTS>;
     constexpr int X0 = 0, X1 = D0T, X2 = D0T + D1T, X3 = D0T + D1T + D2T;        // activation tile offsets
     constexpr int G1 = 0, G2 = D1T, G3 = D1T + D2T, G4 = D1T + D2T + D3T;        // gradient tiles w.r.t. x1, x2, x3 pre-acts, and y
     constexpr int B2 = 0, B3 = D2T, B4 = D2T + D3T;                              // B-operand copies exist for g2, g3, dy only
     extern __shared__ float4 lds_raw[];
     float *lds = reinterpret_cast<float *>(lds_raw);
     float *wl0 = lds + S::w0, *wl1 = lds + S::w1, *wl2 = lds + S::w2, *wl3 = lds + S::w3;
-    float4 (*x)[64] = reinterpret_cast<float4 (*)[64]>(lds + S::x);
-    float (*xT)[16][LG_TT] = reinterpret_cast<float (*)[16][LG_TT]>(lds + S::xT);
-    float4 (*gr)[64] = reinterpret_cast<float4 (*)[64]>(lds + S::gr);
-    float (*gT)[16][LG_TT] = reinterpret_cast<float (*)[16][LG_TT]>(lds + S::gT);
+    const int slot = threadIdx.x / (64 * LG_TRAIN_WAVES);
+    float *area = lds + S::slots + slot * S::slot_floats;
+    float4 (*x)[64] = reinterpret_cast<float4 (*)[64]>(area + S::x);
+    float (*xT)[16][LG_TT] = reinterpret_cast<float (*)[16][LG_TT]>(area + S::xT);
+    float4 (*gr)[64] = reinterpret_cast<float4 (*)[64]>(area + S::gr);
+    float (*gT)[16][LG_TT] = reinterpret_cast<float (*)[16][LG_TT]>(area + S::gT);
+    unsigned long long *tr = (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ? A.trace : nullptr;
+    int tri = 0;
+#define LG_TR() do { if (tr && tri < 60) tr[tri++] = __builtin_readcyclecounter(); } while (0)
+    LG_TR();
     const MlpNetArgs &N = A.net[blockIdx.y];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4;
+    // role of this wave within its group, rotated by the group index: the thin layers (2 and 1 output tiles) land on different SIMDs
+    const int wave = ((threadIdx.x >> 6) + slot) % LG_TRAIN_WAVES, lane = threadIdx.x & 63, g = lane >> 4;
     const int d0 = N.dims[0], d1 = N.dims[1], d2 = N.dims[2], d3 = N.dims[3], d4 = N.dims[4];
-    lds_layer_fill<D0T, D1T>(wl0, N.w[0], N.b[0], d0, d1, threadIdx.x);
-    lds_layer_fill<D1T, D2T>(wl1, N.w[1], N.b[1], d1, d2, threadIdx.x);
-    lds_layer_fill<D2T, D3T>(wl2, N.w[2], N.b[2], d2, d3, threadIdx.x);
-    lds_layer_fill<D3T, 1>(wl3, N.w[3], N.b[3], d3, d4, threadIdx.x);
     using P0 = PairCount<D0T, D1T>; using P1 = PairCount<D1T, D2T>; using P2 = PairCount<D2T, D3T>; using P3 = PairCount<D3T, 1>;
     f32x4 a0[BWD ? P0::per_wave : 1], a1[BWD ? P1::per_wave : 1], a2[BWD ? P2::per_wave : 1], a3[BWD ? P3::per_wave : 1];
     if (BWD) {
@@ -228,43 +235,67 @@ __global__ void __launch_bounds__(64 * LG_TRAIN_WAVES) k_mlp_train(const MlpArgs
     // to hide the gather's two dependent global loads (row index, then the row) behind.
     static_assert(D0T <= LG_TRAIN_WAVES, "one input tile per wave");
     float4 xv_next = make_float4(0.f, 0.f, 0.f, 0.f), dy_next = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto request = [&](int rt) {
-        const int r = rt * 16 + (lane & 15);
-        const bool live = r < A.mb;
+    int64_t src_next = 0;                                          // storage row of this lane in the tile requested NEXT
+    const bool vec_in = (d0 & 3) == 0;
+    auto row_index = [&](int rt) -> int64_t {                      // rows past the batch re-read the last row (their dL/dy is zero)
+        const int r = min(rt * 16 + (lane & 15), A.mb - 1);
+        return A.rows ? A.rows[r] : (int64_t)r;
+    };
+    auto request = [&](int rt, int64_t src) {
         if (wave < D0T) {
-            const int64_t src = live ? (A.rows ? A.rows[r] : (int64_t)r) : (A.rows ? A.rows[A.mb - 1] : (int64_t)(A.mb - 1));
-            const float *xr = N.x + (size_t)src * d0;
-            float v[4];
-#pragma unroll
-            for (int c = 0; c < 4; c++) { const int k = 16 * wave + 4 * g + c; v[c] = k < d0 ? xr[k] : 0.0f; }
-            xv_next = make_float4(v[0], v[1], v[2], v[3]);
+            const float *xr = N.x + (size_t)src * d0 + 16 * wave + 4 * g;
+            const int k = 16 * wave + 4 * g;
+            if (vec_in && k + 3 < d0) xv_next = *reinterpret_cast<const float4 *>(xr);
+            else xv_next = make_float4(k < d0 ? xr[0] : 0.f, k + 1 < d0 ? xr[1] : 0.f, k + 2 < d0 ? xr[2] : 0.f, k + 3 < d0 ? xr[3] : 0.f);
         }
         if (BWD && wave == LG_TRAIN_WAVES - 1) {                   // dL/dy tile (zero for rows past the batch: they contribute nothing)
+            const int r = rt * 16 + (lane & 15);
             float v[4];
 #pragma unroll
-            for (int c = 0; c < 4; c++) { const int k = 4 * g + c; v[c] = (live && k < d4) ? N.dy[(size_t)r * d4 + k] : 0.0f; }
+            for (int c = 0; c < 4; c++) { const int k = 4 * g + c; v[c] = (r < A.mb && k < d4) ? N.dy[(size_t)r * d4 + k] : 0.0f; }
             dy_next = make_float4(v[0], v[1], v[2], v[3]);
         }
     };
-    request(blockIdx.x);
+    const int stride = gridDim.x * SLOTS, n_iter = (A.n_tiles + stride - 1) / stride;     // uniform trip count: barriers inside
+    int rt = blockIdx.x * SLOTS + slot;
+    if (rt < A.n_tiles) request(rt, row_index(rt));                // the only gather that waits for its index in line ...
+    if (rt + stride < A.n_tiles) src_next = row_index(rt + stride);
+    LG_TR();
+    // ... and it is in flight while the weights are copied to LDS
+    lds_layer_fill<D0T, D1T>(wl0, N.w[0], N.b[0], d0, d1, threadIdx.x, blockDim.x);
+    lds_layer_fill<D1T, D2T>(wl1, N.w[1], N.b[1], d1, d2, threadIdx.x, blockDim.x);
+    lds_layer_fill<D2T, D3T>(wl2, N.w[2], N.b[2], d2, d3, threadIdx.x, blockDim.x);
+    lds_layer_fill<D3T, 1>(wl3, N.w[3], N.b[3], d3, d4, threadIdx.x, blockDim.x);
+    LG_TR();
 #pragma unroll 1
-    for (int rt = blockIdx.x; rt < A.n_tiles; rt += gridDim.x) {
+    for (int it = 0; it < n_iter; it++, rt += stride) {
+        const bool active = rt < A.n_tiles;
         const int r = rt * 16 + (lane & 15);
-        const bool live = r < A.mb;
-        const float4 dyv = dy_next;
+        const bool live = active && r < A.mb;
+        const float4 dyv = active ? dy_next : make_float4(0.f, 0.f, 0.f, 0.f);   // an idle group still runs the barriers; it adds zeros
         if (wave < D0T) {
             x[X0 + wave][lane] = xv_next;
             if (BWD) tile_store_t(xT + X0, wave, lane, xv_next);
         }
-        if (rt + (int)gridDim.x < A.n_tiles) request(rt + gridDim.x);
+        LG_TR();
+        if (rt + stride < A.n_tiles) request(rt + stride, src_next);           // its index was loaded an iteration ago
+        if (rt + 2 * stride < A.n_tiles) src_next = row_index(rt + 2 * stride);
+        LG_TR();
         __syncthreads();                                           // (first pass: also the weights are in LDS)
+        LG_TR();
         train_forward_layer<D0T, D1T, true, BWD>(wl0, x + X0, x + X1, xT + (BWD ? X1 : 0), wave, lane);
+        LG_TR();
         __syncthreads();
+        LG_TR();
         train_forward_layer<D1T, D2T, true, BWD>(wl1, x + X1, x + X2, xT + (BWD ? X2 : 0), wave, lane);
+        LG_TR();
         __syncthreads();
+        LG_TR();
         train_forward_layer<D2T, D3T, true, BWD>(wl2, x + X2, x + X3, xT + (BWD ? X3 : 0), wave, lane);
         if (BWD && wave == LG_TRAIN_WAVES - 1) { gr[B4][lane] = dyv; tile_store_t(gT + G4, 0, lane, dyv); }
+        LG_TR();
         __syncthreads();
+        LG_TR();
         if (!BWD) {
             if (wave == 0) {
                 // the output layer reuses x tile X0 as scratch (its inputs are no longer needed in forward-only mode)
@@ -274,29 +305,38 @@ __global__ void __launch_bounds__(64 * LG_TRAIN_WAVES) k_mlp_train(const MlpArgs
 #pragma unroll
                 for (int c = 0; c < 4; c++) { const int k = 4 * g + c; if (live && k < d4) N.y[(size_t)r * d4 + k] = y4[c]; }
             }
+            LG_TR();
             __syncthreads();
+            LG_TR();
             continue;
         }
         // output layer: dW3 / db3 and g3 = (W3^T dy) * elu'(x3)
         train_backward_layer<D3T, 1, true>(wl3, gr + B4, x + X3, gr + B3, gT + G3, wave, lane);
         train_weight_grad<D3T, 1>(gT + G4, xT + X3, a3, wave, lane);
+        LG_TR();
         __syncthreads();
         train_backward_layer<D2T, D3T, true>(wl2, gr + B3, x + X2, gr + B2, gT + G2, wave, lane);
         train_weight_grad<D2T, D3T>(gT + G3, xT + X2, a2, wave, lane);
+        LG_TR();
         __syncthreads();
         train_backward_layer<D1T, D2T, false>(wl1, gr + B2, x + X1, nullptr, gT + G1, wave, lane);
         train_weight_grad<D1T, D2T>(gT + G2, xT + X1, a1, wave, lane);
+        LG_TR();
         __syncthreads();
         train_weight_grad<D0T, D1T>(gT + G1, xT + X0, a0, wave, lane);
+        LG_TR();
         __syncthreads();
+        LG_TR();
     }
     if (BWD) {
-        float *part = N.partial + (size_t)blockIdx.x * N.grad_floats;
+        float *part = N.partial + (size_t)(blockIdx.x * SLOTS + slot) * N.grad_floats;
         train_flush<D0T, D1T>(a0, part, d0, d1, wave, lane); part += (size_t)d1 * d0 + d1;
         train_flush<D1T, D2T>(a1, part, d1, d2, wave, lane); part += (size_t)d2 * d1 + d2;
         train_flush<D2T, D3T>(a2, part, d2, d3, wave, lane); part += (size_t)d3 * d2 + d3;
         train_flush<D3T, 1>(a3, part, d3, d4, wave, lane);
     }
+    LG_TR();
+#undef LG_TR
 }
 
 struct MlpReduceArgs {
@@ -306,21 +346,23 @@ struct MlpReduceArgs {
     int32_t grad_floats[2];
     int32_t n_partials;
 };
-// grads = sum over workgroups of the partials, in a fixed order; thread j owns flat gradient element j of net blockIdx.y
+// grads = sum over workgroups of the partials, in a fixed order.  A workgroup owns 32 consecutive gradient elements; its 8
+// slices (threadIdx >> 5) sum partials k = slice, slice + 8, ... (128-byte coalesced rows) and meet in LDS.
 __global__ void __launch_bounds__(256) k_mlp_reduce(const MlpReduceArgs A) {
-    const int n = blockIdx.y;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float red[8][32];
+    const int n = blockIdx.y, e = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    const int j = blockIdx.x * 32 + e;
     const int gf = A.grad_floats[n];
-    if (j >= gf) return;
-    const float *p = A.partial[n] + j;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int k = 0;
-    for (; k + 4 <= A.n_partials; k += 4) {
-        s0 += p[(size_t)(k + 0) * gf]; s1 += p[(size_t)(k + 1) * gf];
-        s2 += p[(size_t)(k + 2) * gf]; s3 += p[(size_t)(k + 3) * gf];
-    }
-    for (; k < A.n_partials; k++) s0 += p[(size_t)k * gf];
-    const float s = (s0 + s1) + (s2 + s3);
+    const bool ok = j < gf;
+    const float *p = A.partial[n] + (ok ? j : 0);
+    float s0 = 0.f, s1 = 0.f;
+    int k = slice;
+    for (; k + 8 < A.n_partials; k += 16) { s0 += p[(size_t)k * gf]; s1 += p[(size_t)(k + 8) * gf]; }
+    if (k < A.n_partials) s0 += p[(size_t)k * gf];
+    red[slice][e] = s0 + s1;
+    __syncthreads();
+    if (slice != 0 || !ok) return;
+    const float s = ((red[0][e] + red[1][e]) + (red[2][e] + red[3][e])) + ((red[4][e] + red[5][e]) + (red[6][e] + red[7][e]));
     int off = j;
 #pragma unroll
     for (int l = 0; l < 4; l++) {

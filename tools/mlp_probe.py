@@ -33,3 +33,13 @@ flops_fwd = 2 * mb * sum(a * b for net in (actor, critic) for a, b in [(m.in_fea
 tf, tb, tt = timeit(lambda: tr.forward(rows)), timeit(lambda: tr.backward(rows)), timeit(torch_step, 50)
 print(f"mb {mb}: lg_mlp_forward {tf:.1f} us ({flops_fwd / tf / 1e6:.1f} TFLOP/s)  lg_mlp_backward(+recompute, reduce) {tb:.1f} us "
       f"({3 * flops_fwd / tb / 1e6:.1f} TFLOP/s)  torch fwd+bwd {tt:.1f} us")
+
+if os.environ.get("TRACE"):
+    import ctypes as C
+    lib = tr.lib
+    lib.lg_mlp_trace.argtypes, lib.lg_mlp_trace.restype = [C.c_void_p], None
+    for name, fn in (("forward", lambda: tr.forward(rows)), ("backward", lambda: tr.backward(rows))):
+        buf = torch.zeros(64, dtype=torch.int64, device="cuda")
+        lib.lg_mlp_trace(buf.data_ptr()); fn(); torch.cuda.synchronize(); lib.lg_mlp_trace(None)
+        t = buf.cpu().tolist(); t = [v for v in t if v]
+        print(name, "stamps:", len(t), "deltas (s_memtime ticks):", [t[i + 1] - t[i] for i in range(len(t) - 1)], "total", t[-1] - t[0])
