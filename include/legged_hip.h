@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LG_ABI_VERSION        14
+#define LG_ABI_VERSION        15
 
 #define LG_MAX_LIMBS          4
 #define LG_MAX_CHAIN          6
@@ -249,6 +249,30 @@ int  lg_mlp_forward(const lg_mlp_net *nets, int32_t n_nets, const int64_t *rows,
 size_t lg_mlp_workspace_bytes(const lg_mlp_net *nets, int32_t n_nets);
 int  lg_mlp_backward(const lg_mlp_net *nets, int32_t n_nets, const int64_t *rows, int32_t mb, float *workspace, size_t workspace_bytes,
                      void *stream);
+
+/* Diagnostic (tools/mlp_probe.py): while `buf` (device, uint64[60]) is set, lg_mlp_forward / lg_mlp_backward launches write the
+ * s_memtime stamps of their phases as seen by thread 0 of workgroup (0, 0); NULL stops. */
+void lg_mlp_trace(unsigned long long *buf);
+
+/* One transition of the PPO rollout, as rsl_rl's RolloutStorage.add_transitions() + OnPolicyRunner.learn()'s episode
+ * bookkeeping consume it ([EXTERNAL]): the observation the policy saw, its sampled action and mean, and the step's reward /
+ * done / time-out flags (LeggedRobot.step outputs, reference legged_robot.py:106-127).  Device pointers. */
+typedef struct lg_rollout_step {
+    const float   *obs;               /* [N, num_obs]  observation BEFORE the step */
+    const float   *actions;           /* [N, num_actions] */
+    const float   *mean;              /* [N, num_actions] */
+    const float   *rewards;           /* [N] */
+    const uint8_t *dones;             /* [N] reset_buf */
+    const uint8_t *time_outs;         /* [N] time_out_buf, may be NULL */
+    float   *storage_obs, *storage_actions, *storage_mu, *storage_rewards;   /* slices [t] of the rollout storage */
+    uint8_t *storage_dones;
+    float   *storage_time_outs;       /* [N] 0/1, may be NULL */
+    float   *cur_return, *cur_length; /* [N] running episode return / length, may both be NULL */
+    float   *sums;                    /* [3] += {return, length, 1} of every episode that ended this step */
+    int32_t  num_envs, num_obs, num_actions;
+} lg_rollout_step;
+/* Store the transition and update the episode statistics in one launch.  Asynchronous, capturable. */
+int  lg_rollout_record(const lg_rollout_step *step, void *stream);
 
 /* One parameter tensor of torch.optim.Adam(capturable=True): the parameter, its .grad and the optimiser state
  * (state['exp_avg'], state['exp_avg_sq'], state['step'] -- a float32 device scalar).  All updated in place. */

@@ -16,7 +16,7 @@ from typing import Dict, Optional
 
 import numpy as np
 
-LG_ABI_VERSION = 14
+LG_ABI_VERSION = 15
 LG_MAX_LIMBS, LG_MAX_CHAIN, LG_MAX_DOF = 4, 6, 12
 LG_MAX_LIMB_POINTS, LG_MAX_BASE_POINTS, LG_MAX_BODIES = 8, 4, 20
 LG_MAX_HEIGHT_POINTS, LG_ACTUATOR_FLOATS = 192, 972
@@ -180,6 +180,13 @@ class lg_mlp_net(C.Structure):
                 ("input", C.c_void_p), ("output", C.c_void_p), ("grad_output", C.c_void_p), ("dims", i32 * 5)]
 
 
+class lg_rollout_step(C.Structure):
+    """include/legged_hip.h: lg_rollout_step."""
+    _fields_ = [(n, C.c_void_p) for n in ("obs", "actions", "mean", "rewards", "dones", "time_outs", "storage_obs", "storage_actions",
+                                          "storage_mu", "storage_rewards", "storage_dones", "storage_time_outs", "cur_return", "cur_length",
+                                          "sums")] + [("num_envs", i32), ("num_obs", i32), ("num_actions", i32)]
+
+
 class lg_adam_tensor(C.Structure):
     """include/legged_hip.h: lg_adam_tensor."""
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("step", C.c_void_p),
@@ -244,6 +251,9 @@ def bind_prototypes(lib, prefix: str):
         lib.lg_mlp_backward.restype = C.c_int
         lib.lg_adam_step.argtypes = [C.POINTER(lg_adam_tensor), i32, vp, C.c_float, C.c_float, C.c_float, C.c_float, vp, C.c_float, vp, vp]
         lib.lg_adam_step.restype = C.c_int
+        lib.lg_rollout_record.argtypes = [C.POINTER(lg_rollout_step), vp]
+        lib.lg_rollout_record.restype = C.c_int
+        lib.lg_mlp_trace.argtypes, lib.lg_mlp_trace.restype = [vp], None
     for name, (args, res) in sig.items():
         fn = getattr(lib, prefix + name)
         fn.argtypes, fn.restype = args, res
@@ -258,7 +268,7 @@ EXPORTED_SYMBOLS = ["lg_create", "lg_destroy", "lg_bind", "lg_step", "lg_reset_i
                     "lg_physics_substep", "lg_compute_observations_only", "lg_set_params", "lg_last_error",
                     "lg_abi_version", "lg_sizeof", "lg_set_obs_buffer", "lg_policy_create", "lg_policy_destroy", "lg_policy_act",
                     "lg_step_policy", "lg_gae_returns", "lg_ppo_loss", "lg_policy_load_device", "lg_mlp_forward",
-                    "lg_mlp_workspace_bytes", "lg_mlp_backward", "lg_adam_step"]
+                    "lg_mlp_workspace_bytes", "lg_mlp_backward", "lg_adam_step", "lg_rollout_record", "lg_mlp_trace"]
 
 
 def load_library():

@@ -1567,6 +1567,20 @@ int lg_mlp_backward(const lg_mlp_net *nets, int32_t n_nets, const int64_t *rows,
     return 0;
 }
 
+int lg_rollout_record(const lg_rollout_step *s, void *stream) {
+    if (!s || !s->obs || !s->actions || !s->mean || !s->rewards || !s->dones || !s->storage_obs || !s->storage_actions || !s->storage_mu ||
+        !s->storage_rewards || !s->storage_dones) return fail(-1, "null argument");
+    if (s->num_envs <= 0 || s->num_obs <= 0 || s->num_actions <= 0 || s->num_actions > s->num_obs) return fail(-1, "bad sizes");
+    if ((s->cur_return != nullptr) != (s->cur_length != nullptr) || (s->cur_return && !s->sums)) return fail(-1, "incomplete episode statistics");
+    lg::RecordArgs a{s->obs, s->actions, s->mean, s->rewards, s->dones, s->time_outs, s->storage_obs, s->storage_actions, s->storage_mu,
+                     s->storage_rewards, s->storage_dones, s->storage_time_outs, s->cur_return, s->cur_length, s->sums,
+                     s->num_envs, s->num_obs, s->num_actions};
+    const int64_t n = (int64_t)s->num_envs * s->num_obs;
+    hipLaunchKernelGGL(lg::k_rollout_record, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int lg_adam_step(const lg_adam_tensor *tensors, int32_t n_tensors, float *lr, float beta1, float beta2, float eps, float max_grad_norm,
                  const float *kl, float desired_kl, float *scratch, void *stream) {
     if (!tensors || !lr || !scratch || n_tensors < 1 || n_tensors > LG_ADAM_MAX_TENSORS) return fail(-1, "bad argument");

@@ -428,4 +428,32 @@ __global__ void __launch_bounds__(256) k_adam_update(const AdamArgs A) {
     T.param[i] -= (lr / bc1) * m / (sqrtf(v) / sqrtf(bc2) + A.eps);
 }
 
+// ---- rollout bookkeeping: one launch per env step instead of ~18 copies / tiny reductions ---------------------------------
+struct RecordArgs {
+    const float *obs, *actions, *mean, *rewards; const uint8_t *dones, *time_outs;           // this step: [N, .] / [N]
+    float *st_obs, *st_actions, *st_mu, *st_rewards; uint8_t *st_dones; float *st_time_outs;  // storage slices of step t
+    float *cur_rew, *cur_len, *sums;                                                         // running episode return / length [N]; {sum_rew, sum_len, count}
+    int32_t num_envs, num_obs, num_actions;
+};
+__global__ void __launch_bounds__(256) k_rollout_record(const RecordArgs A) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)A.num_envs * A.num_obs) return;
+    const int env = (int)(i / A.num_obs), k = (int)(i % A.num_obs);
+    A.st_obs[i] = A.obs[i];
+    if (k < A.num_actions) {
+        const size_t j = (size_t)env * A.num_actions + k;
+        A.st_actions[j] = A.actions[j]; A.st_mu[j] = A.mean[j];
+    }
+    if (k != 0) return;
+    const float r = A.rewards[env];
+    const uint8_t d = A.dones[env];
+    A.st_rewards[env] = r; A.st_dones[env] = d;
+    if (A.st_time_outs) A.st_time_outs[env] = A.time_outs && A.time_outs[env] ? 1.0f : 0.0f;
+    if (A.cur_rew) {                                   // episode statistics for the log (rsl_rl OnPolicyRunner.learn's rewbuffer / lenbuffer)
+        const float cr = A.cur_rew[env] + r, cl = A.cur_len[env] + 1.0f;
+        if (d) { atomicAdd(A.sums + 0, cr); atomicAdd(A.sums + 1, cl); atomicAdd(A.sums + 2, 1.0f); }
+        A.cur_rew[env] = d ? 0.0f : cr; A.cur_len[env] = d ? 0.0f : cl;
+    }
+}
+
 }  // namespace lg

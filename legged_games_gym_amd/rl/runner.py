@@ -8,6 +8,7 @@ from collections import deque
 
 import torch
 
+from .. import capi
 from .actor_critic import ActorCritic
 from .ppo import PPO
 
@@ -70,21 +71,24 @@ class OnPolicyRunner:
         env, alg, fused = self.env, self.alg, self._fused
         st, T = alg.storage, self.num_steps_per_env
         obs = env.get_observations()
+        lib, step = fused.lib, capi.lg_rollout_step()
+        p = lambda x: x.data_ptr()
+        step.num_envs, step.num_obs, step.num_actions = env.num_envs, st.observations.shape[-1], st.actions.shape[-1]
+        step.cur_return, step.cur_length, step.sums = p(stats["cur_rew"]), p(stats["cur_len"]), p(stats["_sums"])
+        stream = torch.cuda.current_stream(self.device).cuda_stream
         for t in range(T):
-            st.observations[t].copy_(obs)
+            prev_obs = obs
             actions, mean, (obs, _, rewards, dones, infos) = self._fused_env_step(obs)
-            st.actions[t].copy_(actions); st.mu[t].copy_(mean)
-            st.rewards[t].copy_(rewards.view(-1, 1)); st.dones[t].copy_(dones.view(-1, 1))
-            if "time_outs" in infos:
-                self._time_outs[t].copy_(infos["time_outs"].view(-1, 1))
-            d = dones.float()
-            stats["cur_rew"] += rewards
-            stats["cur_len"] += 1.0
-            stats["sum_rew"] += (stats["cur_rew"] * d).sum()
-            stats["sum_len"] += (stats["cur_len"] * d).sum()
-            stats["count"] += d.sum()
-            stats["cur_rew"] *= 1.0 - d
-            stats["cur_len"] *= 1.0 - d
+            # storage writes + episode statistics of this transition: one launch (lg_rollout_record)
+            touts = infos.get("time_outs")
+            step.obs, step.actions, step.mean, step.rewards, step.dones = p(prev_obs), p(actions), p(mean), p(rewards), p(dones)
+            step.time_outs = p(touts) if touts is not None else None
+            step.storage_obs, step.storage_actions, step.storage_mu = p(st.observations[t]), p(st.actions[t]), p(st.mu[t])
+            step.storage_rewards, step.storage_dones, step.storage_time_outs = p(st.rewards[t]), p(st.dones[t]), p(self._time_outs[t])
+            assert dones.element_size() == 1 and (touts is None or touts.element_size() == 1) and rewards.is_contiguous()   # bool / uint8 flags
+            rc = lib.lg_rollout_record(step, stream)
+            if rc != 0:
+                raise RuntimeError(f"lg_rollout_record failed ({rc}): {lib.lg_last_error().decode()}")
         st.step = T
         ac = alg.actor_critic
         st.values.copy_(ac.evaluate(st.observations.flatten(0, 1)).view(T, -1, 1))            # critic once on all transitions
@@ -129,7 +133,9 @@ class OnPolicyRunner:
             return None
         try:
             N, dev = env.num_envs, self.device
-            stats = {k: torch.zeros(N if k.startswith("cur") else (), device=dev) for k in ("cur_rew", "cur_len", "sum_rew", "sum_len", "count")}
+            sums = torch.zeros(3, device=dev)             # {sum of finished-episode returns, of their lengths, their count}
+            stats = {"cur_rew": torch.zeros(N, device=dev), "cur_len": torch.zeros(N, device=dev),
+                     "sum_rew": sums[0], "sum_len": sums[1], "count": sums[2], "_sums": sums}
             with torch.inference_mode():
                 self._rollout_steps(stats)              # one eager warm-up rollout (allocators, lazy init); discarded
                 self.alg.storage.clear()

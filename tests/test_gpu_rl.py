@@ -183,3 +183,39 @@ def test_adam_kernel_matches_torch_adam_with_clipping():
         for a, b in zip(nets[0].parameters(), nets[1].parameters()):
             assert float((opts[0].state[a]["exp_avg_sq"] - opts[1].state[b]["exp_avg_sq"]).abs().max()) < 1e-6
             assert float(opts[0].state[a]["step"]) == float(opts[1].state[b]["step"])
+
+
+def test_rollout_record_kernel_matches_the_torch_bookkeeping():
+    """lg_rollout_record == the copies into the rollout storage + the runner's episode statistics (tensor-op version)."""
+    from legged_games_gym_amd import capi
+    lib = capi.load_library()
+    N, O, A, T = 1000, 48, 12, 5
+    g = torch.Generator(device="cuda").manual_seed(2)
+    r = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    st = {k: torch.zeros(T, N, d, device="cuda") for k, d in (("obs", O), ("act", A), ("mu", A), ("rew", 1), ("tout", 1))}
+    st["done"] = torch.zeros(T, N, 1, device="cuda", dtype=torch.uint8)
+    cur_rew, cur_len, sums = torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda"), torch.zeros(3, device="cuda")
+    ref = {"cur_rew": torch.zeros(N, device="cuda"), "cur_len": torch.zeros(N, device="cuda"), "sums": torch.zeros(3, device="cuda")}
+    step = capi.lg_rollout_step()
+    step.num_envs, step.num_obs, step.num_actions = N, O, A
+    step.cur_return, step.cur_length, step.sums = cur_rew.data_ptr(), cur_len.data_ptr(), sums.data_ptr()
+    keep = []
+    for t in range(T):
+        obs, act, mu, rew = r(N, O), r(N, A), r(N, A), r(N)
+        done = (torch.rand(N, device="cuda", generator=g) < 0.2).to(torch.uint8)
+        tout = (done.bool() & (torch.rand(N, device="cuda", generator=g) < 0.5)).to(torch.uint8)
+        keep.append((obs, act, mu, rew, done, tout))
+        step.obs, step.actions, step.mean, step.rewards, step.dones, step.time_outs = (x.data_ptr() for x in (obs, act, mu, rew, done, tout))
+        step.storage_obs, step.storage_actions, step.storage_mu = st["obs"][t].data_ptr(), st["act"][t].data_ptr(), st["mu"][t].data_ptr()
+        step.storage_rewards, step.storage_dones, step.storage_time_outs = st["rew"][t].data_ptr(), st["done"][t].data_ptr(), st["tout"][t].data_ptr()
+        assert lib.lg_rollout_record(step, torch.cuda.current_stream().cuda_stream) == 0, lib.lg_last_error()
+        d = done.float()
+        ref["cur_rew"] += rew; ref["cur_len"] += 1.0
+        ref["sums"] += torch.stack(((ref["cur_rew"] * d).sum(), (ref["cur_len"] * d).sum(), d.sum()))
+        ref["cur_rew"] *= 1.0 - d; ref["cur_len"] *= 1.0 - d
+    for t, (obs, act, mu, rew, done, tout) in enumerate(keep):
+        assert torch.equal(st["obs"][t], obs) and torch.equal(st["act"][t], act) and torch.equal(st["mu"][t], mu)
+        assert torch.equal(st["rew"][t, :, 0], rew) and torch.equal(st["done"][t, :, 0], done) and torch.equal(st["tout"][t, :, 0], tout.float())
+    assert torch.equal(cur_len, ref["cur_len"]) and float((cur_rew - ref["cur_rew"]).abs().max()) < 1e-6
+    assert float(sums[2]) == float(ref["sums"][2]) and float(sums[1]) == float(ref["sums"][1])
+    assert abs(float(sums[0]) - float(ref["sums"][0])) < 1e-3          # atomic accumulation order

@@ -37,7 +37,6 @@ print(f"mb {mb}: lg_mlp_forward {tf:.1f} us ({flops_fwd / tf / 1e6:.1f} TFLOP/s)
 if os.environ.get("TRACE"):
     import ctypes as C
     lib = tr.lib
-    lib.lg_mlp_trace.argtypes, lib.lg_mlp_trace.restype = [C.c_void_p], None
     for name, fn in (("forward", lambda: tr.forward(rows)), ("backward", lambda: tr.backward(rows))):
         buf = torch.zeros(64, dtype=torch.int64, device="cuda")
         lib.lg_mlp_trace(buf.data_ptr()); fn(); torch.cuda.synchronize(); lib.lg_mlp_trace(None)
