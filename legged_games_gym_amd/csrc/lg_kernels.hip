@@ -1468,7 +1468,7 @@ __global__ void k_policy_pack(const float *__restrict__ W, const float *__restri
 #define LG_TRAIN_WGS 256           /* workgroups per net = partial-sum slices */
 static unsigned long long *g_mlp_trace = nullptr;   /* diagnostic, see lg_mlp_trace */
 #define LG_FWD_SLOTS 4             /* row tiles in flight per workgroup (forward: 140 KB of LDS) */
-#define LG_BWD_SLOTS 1             /* backward: 138 KB with one */
+#define LG_BWD_SLOTS 2             /* backward: 152 KB */
 static int mlp_fill(const lg_mlp_net *nets, int32_t n_nets, const int64_t *rows, int32_t mb, lg::MlpArgs &a, int &wgs, int slots, bool partials) {
     if (!nets || n_nets < 1 || n_nets > 2 || mb <= 0) return fail(-1, "bad argument");
     memset(&a, 0, sizeof a);

@@ -45,18 +45,19 @@ struct MlpArgs {
 template <int IN_T, int OUT_T> struct LdsLayer {
     static constexpr int stride = 16 * IN_T + LG_WPAD, w_floats = 16 * OUT_T * stride, floats = w_floats + 16 * OUT_T;
 };
-template <int IN_T, int OUT_T>
-LG_DEV void lds_layer_fill(float *wl, const float *__restrict__ W, const float *__restrict__ b, int in_dim, int out_dim, int tid, int NT) {
+// The copy is split in two so that the global loads of ALL layers are in flight before the first LDS store waits for one:
+// quads i = tid, tid + NT, ... of the padded [16*OUT_T][16*IN_T] image (+ one bias element per thread).
+template <int IN_T, int OUT_T, int NT> struct LdsFill {
     using L = LdsLayer<IN_T, OUT_T>;
-    constexpr int QPR = 4 * IN_T, NQ = 16 * OUT_T * QPR;                                // quads per row / in the layer
-    const bool vec = (in_dim & 3) == 0;
-    // batches of 4 quads per thread: all the loads of a batch are in flight before the first LDS store needs one
-#pragma unroll 1
-    for (int i0 = tid; i0 < NQ; i0 += 4 * NT) {
-        float4 q[4];
+    static constexpr int QPR = 4 * IN_T, NQ = 16 * OUT_T * QPR, PER = (NQ + NT - 1) / NT;   // quads per row / per layer / per thread
+    static_assert(16 * OUT_T <= NT, "one bias element per thread");
+    float4 q[PER];
+    float bias;
+    LG_DEV void load(const float *__restrict__ W, const float *__restrict__ b, int in_dim, int out_dim, int tid) {
+        const bool vec = (in_dim & 3) == 0;
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int i = i0 + u * NT, row = i / QPR, col = 4 * (i % QPR);
+        for (int u = 0; u < PER; u++) {
+            const int i = tid + u * NT, row = i / QPR, col = 4 * (i % QPR);
             q[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (i < NQ && row < out_dim) {
                 const float *src = W + (size_t)row * in_dim + col;
@@ -69,14 +70,17 @@ LG_DEV void lds_layer_fill(float *wl, const float *__restrict__ W, const float *
                 }
             }
         }
+        bias = tid < out_dim ? b[tid] : 0.0f;
+    }
+    LG_DEV void store(float *wl, int tid) const {
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int i = i0 + u * NT, row = i / QPR, col = 4 * (i % QPR);
+        for (int u = 0; u < PER; u++) {
+            const int i = tid + u * NT, row = i / QPR, col = 4 * (i % QPR);
             if (i < NQ) *reinterpret_cast<float4 *>(wl + row * L::stride + col) = q[u];
         }
+        if (tid < 16 * OUT_T) wl[L::w_floats + tid] = bias;
     }
-    for (int i = tid; i < 16 * OUT_T; i += NT) wl[L::w_floats + i] = i < out_dim ? b[i] : 0.0f;
-}
+};
 
 // feature-major copy of a tile: xt[feature 16][LG_TT] <- lane (row l&15, group g) holds features 4g..4g+3
 LG_DEV void tile_store_t(float (*xt)[16][LG_TT], int tile, int lane, float4 v) {
@@ -84,9 +88,39 @@ LG_DEV void tile_store_t(float (*xt)[16][LG_TT], int tile, int lane, float4 v) {
     xt[tile][4 * g + 0][r] = v.x; xt[tile][4 * g + 1][r] = v.y; xt[tile][4 * g + 2][r] = v.z; xt[tile][4 * g + 3][r] = v.w;
 }
 
+// MFMA B operand / D-layout view of a feature-major tile: lane (row r = l&15, group g) <- features 4g..4g+3 of row r
+// (4 ds_read_b32 at stride LG_TT: within a 32-lane half the banks are r and 16 + r -- conflict-free)
+LG_DEV float4 tile_load_b(const float (*xt)[16][LG_TT], int tile, int lane) {
+    const int g = lane >> 4, r = lane & 15;
+    return make_float4(xt[tile][4 * g + 0][r], xt[tile][4 * g + 1][r], xt[tile][4 * g + 2][r], xt[tile][4 * g + 3][r]);
+}
+
+// backward build: activations exist only feature-major (the B-operand copies would not leave room for two row tiles in flight)
+template <int IN_T, int OUT_T>
+LG_DEV void train_forward_layer_t(const float *wl, const float (*xinT)[16][LG_TT], float (*xoutT)[16][LG_TT], int wave, int lane) {
+    using L = LdsLayer<IN_T, OUT_T>;
+    const int g = lane >> 4;
+#pragma unroll 1
+    for (int o = wave; o < OUT_T; o += LG_TRAIN_WAVES) {
+        const float *wr = wl + (16 * o + (lane & 15)) * L::stride + 4 * g;
+        const float4 bv = *reinterpret_cast<const float4 *>(wl + L::w_floats + 16 * o + 4 * g);
+        f32x4 acc = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+        for (int t = 0; t < IN_T; t++) {
+            const float4 wv = *reinterpret_cast<const float4 *>(wr + 16 * t);
+            const float4 xv = tile_load_b(xinT, t, lane);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.x, xv.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.y, xv.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.z, xv.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.w, xv.w, acc, 0, 0, 0);
+        }
+        tile_store_t(xoutT, o, lane, make_float4(elu1(acc[0]), elu1(acc[1]), elu1(acc[2]), elu1(acc[3])));
+    }
+}
+
 // x_out = act(W x_in + b), all operands in LDS
-template <int IN_T, int OUT_T, bool ACT, bool KEEP_T>
-LG_DEV void train_forward_layer(const float *wl, const float4 (*xin)[64], float4 (*xout)[64], float (*xoutT)[16][LG_TT], int wave, int lane) {
+template <int IN_T, int OUT_T, bool ACT>
+LG_DEV void train_forward_layer(const float *wl, const float4 (*xin)[64], float4 (*xout)[64], int wave, int lane) {
     using L = LdsLayer<IN_T, OUT_T>;
     const int g = lane >> 4;
 #pragma unroll 1
@@ -105,15 +139,14 @@ LG_DEV void train_forward_layer(const float *wl, const float4 (*xin)[64], float4
         }
         const float4 res = ACT ? make_float4(elu1(acc[0]), elu1(acc[1]), elu1(acc[2]), elu1(acc[3])) : make_float4(acc[0], acc[1], acc[2], acc[3]);
         xout[o][lane] = res;
-        if (KEEP_T) tile_store_t(xoutT, o, lane, res);
     }
 }
 
-// g_in = (W^T g_out) * elu'(x_in): OUT_T gradient tiles -> IN_T gradient tiles (x_in = stored post-activation of the layer input)
-// (KEEP_B: also keep the MFMA B-operand form of the result -- not needed for the first hidden layer, whose input gets no gradient)
-template <int IN_T, int OUT_T, bool KEEP_B>
-LG_DEV void train_backward_layer(const float *wl, const float4 (*gout)[64], const float4 (*xin)[64],
-                                 float4 (*gin)[64], float (*ginT)[16][LG_TT], int wave, int lane) {
+// g_in = (W^T g_out) * elu'(x_in): OUT_T gradient tiles -> IN_T gradient tiles (x_in = stored post-activation of the layer input);
+// all tiles feature-major
+template <int IN_T, int OUT_T>
+LG_DEV void train_backward_layer(const float *wl, const float (*goutT)[16][LG_TT], const float (*xinT)[16][LG_TT],
+                                 float (*ginT)[16][LG_TT], int wave, int lane) {
     using L = LdsLayer<IN_T, OUT_T>;
     const int g = lane >> 4;
 #pragma unroll 1
@@ -122,17 +155,15 @@ LG_DEV void train_backward_layer(const float *wl, const float4 (*gout)[64], cons
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int o = 0; o < OUT_T; o++) {
-            const float4 gv = gout[o][lane];
+            const float4 gv = tile_load_b(goutT, o, lane);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[(16 * o + 0) * L::stride], gv.x, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[(16 * o + 1) * L::stride], gv.y, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[(16 * o + 2) * L::stride], gv.z, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[(16 * o + 3) * L::stride], gv.w, acc, 0, 0, 0);
         }
-        const float4 xv = xin[ti][lane];
-        const float4 res = make_float4(acc[0] * (xv.x > 0.f ? 1.f : xv.x + 1.f), acc[1] * (xv.y > 0.f ? 1.f : xv.y + 1.f),
-                                       acc[2] * (xv.z > 0.f ? 1.f : xv.z + 1.f), acc[3] * (xv.w > 0.f ? 1.f : xv.w + 1.f));
-        if (KEEP_B) gin[ti][lane] = res;
-        tile_store_t(ginT, ti, lane, res);
+        const float4 xv = tile_load_b(xinT, ti, lane);
+        tile_store_t(ginT, ti, lane, make_float4(acc[0] * (xv.x > 0.f ? 1.f : xv.x + 1.f), acc[1] * (xv.y > 0.f ? 1.f : xv.y + 1.f),
+                                                 acc[2] * (xv.z > 0.f ? 1.f : xv.z + 1.f), acc[3] * (xv.w > 0.f ? 1.f : xv.w + 1.f)));
     }
 }
 
@@ -184,13 +215,14 @@ LG_DEV void train_flush(const f32x4 *acc, float *__restrict__ part, int in_dim, 
     }
 }
 
-// LDS budget of k_mlp_train in floats (dynamic shared memory; the backward build needs ~138 KB of the CU's 160 KB)
+// LDS budget of k_mlp_train in floats (dynamic shared memory; 72 KB of weights + 17 KB (forward) / 40 KB (backward) per row tile in flight)
 template <int D0T, int D1T, int D2T, int D3T, bool BWD, int SLOTS> struct TrainLds {
-    static constexpr int XT = D0T + D1T + D2T + D3T, GT = D1T + D2T + D3T + 1, BT = D2T + D3T + 1;
+    static constexpr int XT = D0T + D1T + D2T + D3T, GT = D1T + D2T + D3T + 1;
     static constexpr int w0 = 0, w1 = w0 + LdsLayer<D0T, D1T>::floats, w2 = w1 + LdsLayer<D1T, D2T>::floats, w3 = w2 + LdsLayer<D2T, D3T>::floats,
                          slots = w3 + LdsLayer<D3T, 1>::floats;                  // weights, then SLOTS row-tile work areas:
-    static constexpr int x = 0, xT = x + XT * 256, gr = xT + (BWD ? XT * 16 * LG_TT : 0), gT = gr + (BWD ? BT * 256 : 0),
-                         slot_floats = gT + (BWD ? GT * 16 * LG_TT : 0), floats = slots + SLOTS * slot_floats;
+    // forward build: activations as MFMA B operands [tile][lane] float4; backward build: activations and gradients feature-major
+    static constexpr int x = 0, xT = 0, gT = XT * 16 * LG_TT,
+                         slot_floats = BWD ? (XT + GT) * 16 * LG_TT : XT * 256, floats = slots + SLOTS * slot_floats;
 };
 
 // One persistent workgroup per (slice blockIdx.x, net blockIdx.y): weights -> LDS once, then it walks its row tiles.  SLOTS
@@ -201,7 +233,6 @@ __global__ void __launch_bounds__(64 * LG_TRAIN_WAVES * SLOTS) k_mlp_train(const
     using S = TrainLds<D0T, D1T, D2T, D3T, BWD, SLOTS>;
     constexpr int X0 = 0, X1 = D0T, X2 = D0T + D1T, X3 = D0T + D1T + D2T;        // activation tile offsets
     constexpr int G1 = 0, G2 = D1T, G3 = D1T + D2T, G4 = D1T + D2T + D3T;        // gradient tiles w.r.t. x1, x2, x3 pre-acts, and y
-    constexpr int B2 = 0, B3 = D2T, B4 = D2T + D3T;                              // B-operand copies exist for g2, g3, dy only
     extern __shared__ float4 lds_raw[];
     float *lds = reinterpret_cast<float *>(lds_raw);
     float *wl0 = lds + S::w0, *wl1 = lds + S::w1, *wl2 = lds + S::w2, *wl3 = lds + S::w3;
@@ -209,7 +240,6 @@ __global__ void __launch_bounds__(64 * LG_TRAIN_WAVES * SLOTS) k_mlp_train(const
     float *area = lds + S::slots + slot * S::slot_floats;
     float4 (*x)[64] = reinterpret_cast<float4 (*)[64]>(area + S::x);
     float (*xT)[16][LG_TT] = reinterpret_cast<float (*)[16][LG_TT]>(area + S::xT);
-    float4 (*gr)[64] = reinterpret_cast<float4 (*)[64]>(area + S::gr);
     float (*gT)[16][LG_TT] = reinterpret_cast<float (*)[16][LG_TT]>(area + S::gT);
     unsigned long long *tr = (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ? A.trace : nullptr;
     int tri = 0;
@@ -262,10 +292,13 @@ __global__ void __launch_bounds__(64 * LG_TRAIN_WAVES * SLOTS) k_mlp_train(const
     if (rt + stride < A.n_tiles) src_next = row_index(rt + stride);
     LG_TR();
     // ... and it is in flight while the weights are copied to LDS
-    lds_layer_fill<D0T, D1T>(wl0, N.w[0], N.b[0], d0, d1, threadIdx.x, blockDim.x);
-    lds_layer_fill<D1T, D2T>(wl1, N.w[1], N.b[1], d1, d2, threadIdx.x, blockDim.x);
-    lds_layer_fill<D2T, D3T>(wl2, N.w[2], N.b[2], d2, d3, threadIdx.x, blockDim.x);
-    lds_layer_fill<D3T, 1>(wl3, N.w[3], N.b[3], d3, d4, threadIdx.x, blockDim.x);
+    {
+        constexpr int NT = 64 * LG_TRAIN_WAVES * SLOTS;
+        LdsFill<D0T, D1T, NT> f0; LdsFill<D1T, D2T, NT> f1; LdsFill<D2T, D3T, NT> f2; LdsFill<D3T, 1, NT> f3;
+        f0.load(N.w[0], N.b[0], d0, d1, threadIdx.x); f1.load(N.w[1], N.b[1], d1, d2, threadIdx.x);
+        f2.load(N.w[2], N.b[2], d2, d3, threadIdx.x); f3.load(N.w[3], N.b[3], d3, d4, threadIdx.x);
+        f0.store(wl0, threadIdx.x); f1.store(wl1, threadIdx.x); f2.store(wl2, threadIdx.x); f3.store(wl3, threadIdx.x);
+    }
     LG_TR();
 #pragma unroll 1
     for (int it = 0; it < n_iter; it++, rt += stride) {
@@ -274,8 +307,7 @@ __global__ void __launch_bounds__(64 * LG_TRAIN_WAVES * SLOTS) k_mlp_train(const
         const bool live = active && r < A.mb;
         const float4 dyv = active ? dy_next : make_float4(0.f, 0.f, 0.f, 0.f);   // an idle group still runs the barriers; it adds zeros
         if (wave < D0T) {
-            x[X0 + wave][lane] = xv_next;
-            if (BWD) tile_store_t(xT + X0, wave, lane, xv_next);
+            if (BWD) tile_store_t(xT + X0, wave, lane, xv_next); else x[X0 + wave][lane] = xv_next;
         }
         LG_TR();
         if (rt + stride < A.n_tiles) request(rt + stride, src_next);           // its index was loaded an iteration ago
@@ -283,23 +315,26 @@ __global__ void __launch_bounds__(64 * LG_TRAIN_WAVES * SLOTS) k_mlp_train(const
         LG_TR();
         __syncthreads();                                           // (first pass: also the weights are in LDS)
         LG_TR();
-        train_forward_layer<D0T, D1T, true, BWD>(wl0, x + X0, x + X1, xT + (BWD ? X1 : 0), wave, lane);
+        if (BWD) train_forward_layer_t<D0T, D1T>(wl0, xT + X0, xT + X1, wave, lane);
+        else train_forward_layer<D0T, D1T, true>(wl0, x + X0, x + X1, wave, lane);
         LG_TR();
         __syncthreads();
         LG_TR();
-        train_forward_layer<D1T, D2T, true, BWD>(wl1, x + X1, x + X2, xT + (BWD ? X2 : 0), wave, lane);
+        if (BWD) train_forward_layer_t<D1T, D2T>(wl1, xT + X1, xT + X2, wave, lane);
+        else train_forward_layer<D1T, D2T, true>(wl1, x + X1, x + X2, wave, lane);
         LG_TR();
         __syncthreads();
         LG_TR();
-        train_forward_layer<D2T, D3T, true, BWD>(wl2, x + X2, x + X3, xT + (BWD ? X3 : 0), wave, lane);
-        if (BWD && wave == LG_TRAIN_WAVES - 1) { gr[B4][lane] = dyv; tile_store_t(gT + G4, 0, lane, dyv); }
+        if (BWD) train_forward_layer_t<D2T, D3T>(wl2, xT + X2, xT + X3, wave, lane);
+        else train_forward_layer<D2T, D3T, true>(wl2, x + X2, x + X3, wave, lane);
+        if (BWD && wave == LG_TRAIN_WAVES - 1) tile_store_t(gT + G4, 0, lane, dyv);
         LG_TR();
         __syncthreads();
         LG_TR();
         if (!BWD) {
             if (wave == 0) {
                 // the output layer reuses x tile X0 as scratch (its inputs are no longer needed in forward-only mode)
-                train_forward_layer<D3T, 1, false, false>(wl3, x + X3, x + X0, nullptr, 0, lane);
+                train_forward_layer<D3T, 1, false>(wl3, x + X3, x + X0, 0, lane);
                 const float4 yv = x[X0][lane];
                 const float y4[4] = {yv.x, yv.y, yv.z, yv.w};
 #pragma unroll
@@ -311,15 +346,15 @@ __global__ void __launch_bounds__(64 * LG_TRAIN_WAVES * SLOTS) k_mlp_train(const
             continue;
         }
         // output layer: dW3 / db3 and g3 = (W3^T dy) * elu'(x3)
-        train_backward_layer<D3T, 1, true>(wl3, gr + B4, x + X3, gr + B3, gT + G3, wave, lane);
+        train_backward_layer<D3T, 1>(wl3, gT + G4, xT + X3, gT + G3, wave, lane);
         train_weight_grad<D3T, 1>(gT + G4, xT + X3, a3, wave, lane);
         LG_TR();
         __syncthreads();
-        train_backward_layer<D2T, D3T, true>(wl2, gr + B3, x + X2, gr + B2, gT + G2, wave, lane);
+        train_backward_layer<D2T, D3T>(wl2, gT + G3, xT + X2, gT + G2, wave, lane);
         train_weight_grad<D2T, D3T>(gT + G3, xT + X2, a2, wave, lane);
         LG_TR();
         __syncthreads();
-        train_backward_layer<D1T, D2T, false>(wl1, gr + B2, x + X1, nullptr, gT + G1, wave, lane);
+        train_backward_layer<D1T, D2T>(wl1, gT + G2, xT + X1, gT + G1, wave, lane);
         train_weight_grad<D1T, D2T>(gT + G2, xT + X1, a1, wave, lane);
         LG_TR();
         __syncthreads();
