@@ -428,7 +428,13 @@ __global__ void __launch_bounds__(1024) k_adam_prepare(const AdamArgs A) {
     float s = 0.0f;
     for (int k = 0; k < A.n_tensors; k++) {
         const float *g = A.t[k].grad;
-        for (int64_t i = threadIdx.x; i < A.t[k].numel; i += 1024) s = fmaf(g[i], g[i], s);
+        const int64_t n = A.t[k].numel;
+        int64_t i = threadIdx.x;
+        for (; i + 3 * 1024 < n; i += 4 * 1024) {                  // four loads in flight (fixed summation order per thread)
+            const float g0 = g[i], g1 = g[i + 1024], g2 = g[i + 2048], g3 = g[i + 3072];
+            s = fmaf(g0, g0, s); s = fmaf(g1, g1, s); s = fmaf(g2, g2, s); s = fmaf(g3, g3, s);
+        }
+        for (; i < n; i += 1024) s = fmaf(g[i], g[i], s);
     }
     red[threadIdx.x] = s;
     __syncthreads();

@@ -316,6 +316,11 @@ class PPO:
             torch.autograd.backward([mu, val], [d_mu, d_val])
         ac.std.grad = self._d_std
         adaptive = self.desired_kl is not None and self.schedule == "adaptive"
+        if _world() > 1:                             # data-parallel ranks: mean gradient and mean KL (rollout shards are equal-sized)
+            self._allreduce_grads()
+            if adaptive:
+                dist.all_reduce(self._stats[2:3], op=dist.ReduceOp.SUM)
+                self._stats[2:3] /= _world()
         table = self._adam_table() if self._adam_kernel else None
         if table is not None:
             g = self.optimizer.param_groups[0]
@@ -423,10 +428,36 @@ class PPO:
         st.clear()
         return mean_v, mean_s
 
+    def _update_fused_eager(self, perm=None):
+        """world_size > 1: the kernel mini-batch step (learner kernels / fused loss / lg_adam_step) launched eagerly, with the
+        gradient and KL all-reduces between backward and the optimiser step (collectives are not captured into a graph)."""
+        st = self.storage
+        B = st.num_envs * st.num_transitions_per_env
+        mb = B // self.num_mini_batches
+        if not hasattr(self, "_ix") or self._ix.numel() != mb:
+            self._ix = torch.zeros(mb, dtype=torch.int64, device=self.device)
+            self._acc = torch.zeros(2, device=self.device)
+        self._acc.zero_()
+        if perm is None:
+            perm = torch.randperm(self.num_mini_batches * mb, device=self.device)
+        for _ in range(self.num_learning_epochs):
+            for i in range(self.num_mini_batches):
+                self._ix.copy_(perm[i * mb:(i + 1) * mb])
+                self._zero_grad()
+                self._mb_step()
+        n = self.num_learning_epochs * self.num_mini_batches
+        mean_v, mean_s, lr = (float(x) for x in torch.cat((self._acc / n, self._lr.view(1))).cpu())
+        self.learning_rate = lr
+        self._updates_done += 1
+        st.clear()
+        return mean_v, mean_s
+
     def update(self, perm=None):
         """One PPO update over the stored rollout.  ``perm`` (optional) fixes the mini-batch permutation (tests)."""
         if self._graph_ok and _world() == 1:
             return self._update_graphed(perm)
+        if self._graph_ok and self._fused_ready():
+            return self._update_fused_eager(perm)
         mean_v, mean_s = 0.0, 0.0
         gen = self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs, perm)
         for obs, cobs, act, tval, adv, ret, old_lp, old_mu, old_sig, _, _ in gen:
