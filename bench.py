@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--graph-steps", type=int, default=20, help="policy steps captured per HIP-graph replay (clamped to a divisor of --steps and --warmup)")
     ap.add_argument("--no-fused-step", action="store_true", help="keep actor kernel and step kernel separate (lg_policy_act + lg_step)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one captured HIP graph per step")
+    ap.add_argument("--training-iters", type=int, default=100, help="PPO iterations timed for the extra ppo_training object (0 = skip; N=1, anymal_c_flat only)")
     ap.add_argument("--event-steps", type=int, default=200, help="eager steps timed with HIP events for the roofline object")
     a = ap.parse_args()
 
@@ -63,6 +64,11 @@ def main():
             dist.init_process_group(backend)
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
+    # torch's CUDA generator creates its graph-safe state at the first capture in the process; done under inference_mode (the
+    # rollout graphs below) those tensors could not be touched by the later training leg.  Prime them in normal mode, keep alive.
+    rng_prime = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(rng_prime):
+        torch.zeros(1, device=dev).add_(1.0)
 
     import contextlib
     import io
@@ -180,12 +186,44 @@ def main():
                          "algorithmic_bytes_per_env_step": bpe,
                          "note": "issue/latency-bound, not HBM-bound: 4096 envs = 256 workgroups x (1 rigid-body + 3 helper waves), one wave per SIMD, ~20k serial instructions on the rigid-body wave at one per ~6.5 cycles; see DESIGN.md section 5"},
         }
+        if world == 1 and a.training_iters > 0 and a.task == "anymal_c_flat":
+            try:                                 # extra information, never allowed to take the headline line down
+                out["ppo_training"] = training_leg(a)
+            except Exception as exc:
+                out["ppo_training"] = {"error": f"{type(exc).__name__}: {exc}"}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def training_leg(a):
+    """Not the headline metric: env-steps/s of the whole PPO loop (24-step rollouts + 5 x 4 mini-batch updates per iteration,
+    reference anymal_c_flat train cfg) with the bundled runner -- rollout graph of lg_step_policy + lg_rollout_record, update =
+    lg_mlp_forward / lg_ppo_loss / lg_mlp_backward / lg_adam_step replayed as one HIP graph per mini-batch."""
+    import torch
+    from legged_games_gym_amd.envs import task_registry
+    from legged_games_gym_amd.utils import get_args
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):              # rank 0 prints ONE line: everything here stays silent
+        args = get_args(["--task", a.task, "--headless", "--sim_device", "cuda:0", "--rl_device", "cuda:0", "--num_envs", str(a.num_envs)])
+        env, _ = task_registry.make_env(a.task, args)
+        runner, train_cfg = task_registry.make_alg_runner(env, a.task, args, log_root=None)
+        runner.learn(num_learning_iterations=6, init_at_random_ep_len=True)      # eager warm-up update, graph captures
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        runner.learn(num_learning_iterations=a.training_iters)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    T = int(train_cfg.runner.num_steps_per_env)
+    alg = runner.alg
+    return {"value": a.num_envs * T * a.training_iters / dt, "unit": "env-steps/s (rollout + PPO update)", "iterations": a.training_iters,
+            "ms_per_iteration": 1e3 * dt / a.training_iters, "steps_per_env": T, "epochs_x_minibatches": [alg.num_learning_epochs, alg.num_mini_batches],
+            "update_path": "MFMA learner kernels" if getattr(alg, "_mlp", None) is not None else "torch autograd",
+            "final_learning_rate": float(alg.learning_rate),
+            "note": "includes re-capturing the rollout graph at the start of the timed learn() call"}
 
 
 def _usable_cores():

@@ -219,3 +219,31 @@ def test_rollout_record_kernel_matches_the_torch_bookkeeping():
     assert torch.equal(cur_len, ref["cur_len"]) and float((cur_rew - ref["cur_rew"]).abs().max()) < 1e-6
     assert float(sums[2]) == float(ref["sums"][2]) and float(sums[1]) == float(ref["sums"][1])
     assert abs(float(sums[0]) - float(ref["sums"][0])) < 1e-3          # atomic accumulation order
+
+
+def test_mlp_kernels_ragged_widths_and_a_single_net():
+    """Input width not a multiple of 4 (guarded scalar loads, zero-padded LDS image), 7 outputs, one net per launch, no gather."""
+    import torch.nn as nn
+    from legged_games_gym_amd.rl.mlp_kernels import MlpTrainer
+    torch.manual_seed(4)
+    net = nn.Sequential(nn.Linear(45, 128), nn.ELU(), nn.Linear(128, 64), nn.ELU(), nn.Linear(64, 32), nn.ELU(), nn.Linear(32, 7)).cuda()
+    mb = 16 * 300 + 5
+    x = torch.randn(mb, 45, device="cuda")
+    tr = MlpTrainer([net], [x], mb)
+    assert tr.supported
+    (y,) = tr.forward(None)
+    ref = net(x)
+    assert float((y - ref.detach()).abs().max()) < 2e-5
+    dy = torch.randn(mb, 7, device="cuda") / mb
+    ref.backward(dy)
+    want = [p.grad.clone() for p in net.parameters()]
+    for p in net.parameters():
+        p.grad.fill_(float("nan"))
+    tr.refresh()
+    tr.grad_outputs[0].copy_(dy)
+    tr.backward(None)
+    for w, p in zip(want, net.parameters()):
+        assert float((w - p.grad).abs().max()) < 2e-4 * float(w.abs().max()) + 1e-9
+    # a shape the kernels are not built for is reported, not mis-computed
+    wide = nn.Sequential(nn.Linear(48, 512), nn.ELU(), nn.Linear(512, 256), nn.ELU(), nn.Linear(256, 128), nn.ELU(), nn.Linear(128, 12)).cuda()
+    assert not MlpTrainer([wide], [torch.randn(64, 48, device="cuda")], 64).supported
