@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LG_ABI_VERSION        15
+#define LG_ABI_VERSION        16
 
 #define LG_MAX_LIMBS          4
 #define LG_MAX_CHAIN          6
@@ -285,10 +285,12 @@ typedef struct lg_adam_tensor {
     int64_t      numel;
 } lg_adam_tensor;
 
-/* The tail of rsl_rl PPO.update()'s mini-batch step ([EXTERNAL]) in two launches: nn.utils.clip_grad_norm_(params, max_grad_norm)
+/* The tail of rsl_rl PPO.update()'s mini-batch step ([EXTERNAL]) in three launches: nn.utils.clip_grad_norm_(params, max_grad_norm)
  * over all `tensors` together, the adaptive-KL learning-rate rule (kl == NULL or desired_kl <= 0: fixed schedule;
  * legged_robot_config.py:221-226) on the device scalar `lr`, and torch.optim.Adam.step() (weight_decay 0, amsgrad off) on the
- * clipped gradients.  scratch [2] receives {total gradient norm, clip coefficient}.  n_tensors <= 32.  Capturable. */
+ * clipped gradients.  scratch [LG_ADAM_SCRATCH_FLOATS] is work space; its first two floats receive {total gradient norm, clip
+ * coefficient}.  n_tensors <= 32.  Three launches, fixed summation order (bit-reproducible).  Capturable. */
+#define LG_ADAM_SCRATCH_FLOATS 2050
 int  lg_adam_step(const lg_adam_tensor *tensors, int32_t n_tensors, float *lr, float beta1, float beta2, float eps, float max_grad_norm,
                   const float *kl, float desired_kl, float *scratch, void *stream);
 

@@ -16,7 +16,8 @@ from typing import Dict, Optional
 
 import numpy as np
 
-LG_ABI_VERSION = 15
+LG_ABI_VERSION = 16
+LG_ADAM_SCRATCH_FLOATS = 2050
 LG_MAX_LIMBS, LG_MAX_CHAIN, LG_MAX_DOF = 4, 6, 12
 LG_MAX_LIMB_POINTS, LG_MAX_BASE_POINTS, LG_MAX_BODIES = 8, 4, 20
 LG_MAX_HEIGHT_POINTS, LG_ACTUATOR_FLOATS = 192, 972

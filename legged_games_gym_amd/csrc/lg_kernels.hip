@@ -1595,6 +1595,9 @@ int lg_adam_step(const lg_adam_tensor *tensors, int32_t n_tensors, float *lr, fl
     a.n_tensors = n_tensors; a.lr = lr; a.kl = kl; a.scratch = scratch;
     a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.max_norm = max_grad_norm; a.desired_kl = desired_kl;
     hipStream_t st = (hipStream_t)stream;
+    static_assert(LG_ADAM_SCRATCH_FLOATS >= 2 + LG_ADAM_MAX_TENSORS * LG_ADAM_CHUNKS, "scratch contract");
+    const int64_t chunk_len = (max_n + LG_ADAM_CHUNKS - 1) / LG_ADAM_CHUNKS;
+    hipLaunchKernelGGL(lg::k_adam_sumsq, dim3(LG_ADAM_CHUNKS, n_tensors), dim3(256), 0, st, a, chunk_len);
     hipLaunchKernelGGL(lg::k_adam_prepare, dim3(1), dim3(1024), 0, st, a);
     hipLaunchKernelGGL(lg::k_adam_update, dim3((unsigned)((max_n + 255) / 256), n_tensors), dim3(256), 0, st, a);
     HIP_TRY(hipGetLastError());

@@ -281,7 +281,7 @@ class PPO:
             t.param, t.grad, t.exp_avg, t.exp_avg_sq = q.data_ptr(), q.grad.data_ptr(), stt["exp_avg"].data_ptr(), stt["exp_avg_sq"].data_ptr()
             t.step, t.numel = stt["step"].data_ptr(), q.numel()
         if getattr(self, "_adam_scratch", None) is None:
-            self._adam_scratch = torch.zeros(2, device=self.device)
+            self._adam_scratch = torch.zeros(capi.LG_ADAM_SCRATCH_FLOATS, device=self.device)
         return table
 
     def _mb_step_fused(self):

@@ -144,16 +144,22 @@ def test_mlp_kernels_match_autograd(mb, gather):
     assert all(torch.equal(a, b) for a, b in zip(first, got))
 
 
-def test_adam_kernel_matches_torch_adam_with_clipping():
-    """lg_adam_step against clip_grad_norm_ + torch.optim.Adam(capturable=True).step() on the optimiser's own state tensors."""
+@pytest.mark.parametrize("wide", [False, True])
+def test_adam_kernel_matches_torch_adam_with_clipping(wide):
+    """lg_adam_step against clip_grad_norm_ + torch.optim.Adam(capturable=True).step() on the optimiser's own state tensors
+    (wide: the 235-512-256-128 networks of the rough tasks, 290 k parameters)."""
     import torch.nn as nn
     from legged_games_gym_amd import capi
     lib = capi.load_library()
-    nets = [_mlp(48, 12, 3), _mlp(48, 12, 3)]
+
+    def wide_mlp():
+        torch.manual_seed(3)
+        return nn.Sequential(nn.Linear(235, 512), nn.ELU(), nn.Linear(512, 256), nn.ELU(), nn.Linear(256, 128), nn.ELU(), nn.Linear(128, 12)).cuda()
+    nets = [wide_mlp(), wide_mlp()] if wide else [_mlp(48, 12, 3), _mlp(48, 12, 3)]
     lrs = [torch.tensor(1e-3, device="cuda"), torch.tensor(1e-3, device="cuda")]
     opts = [torch.optim.Adam(n.parameters(), lr=l, capturable=True) for n, l in zip(nets, lrs)]
     g = torch.Generator(device="cuda").manual_seed(9)
-    scratch = torch.zeros(2, device="cuda")
+    scratch = torch.zeros(capi.LG_ADAM_SCRATCH_FLOATS, device="cuda")
     for it in range(6):
         grads = [torch.randn(q.shape, device="cuda", generator=g) * (3.0 if it % 2 else 0.01) for q in nets[0].parameters()]
         for n in nets:
