@@ -122,6 +122,37 @@ class RolloutStorage:
                 yield obs[ix], cobs[ix], act[ix], val[ix], adv[ix], ret[ix], lp[ix], mu[ix], sig[ix], (None, None), None
 
 
+class _LinearSplitK(torch.autograd.Function):
+    """``F.linear`` whose weight gradient is computed as a batched GEMM over row chunks.  dW = g^T x has the whole mini-batch
+    (24 576 rows) as its K dimension and only out x in <= 512 x 512 outputs: hipBLASLt runs it on 16 workgroups (324 us for
+    512 x 235); cutting the rows into S chunks gives S times the tiles (torch.bmm) and a cheap [S, out, in] sum."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return torch.addmm(b, x, w.t())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        M = x.shape[0]
+        S = next((s for s in (16, 12, 8, 6, 4, 3, 2) if M % s == 0 and M // s >= 256), 1)
+        g = g.contiguous()
+        if S > 1:
+            gw = torch.bmm(g.view(S, M // S, -1).transpose(1, 2), x.view(S, M // S, -1)).sum(0)
+        else:
+            gw = g.t() @ x
+        gx = g @ w if ctx.needs_input_grad[0] else None
+        return gx, gw, g.sum(0)
+
+
+def _mlp_split_k(seq, x):
+    """Apply an ``nn.Sequential`` of Linear / activation modules with ``_LinearSplitK`` in place of ``nn.Linear``."""
+    for m in seq:
+        x = _LinearSplitK.apply(x, m.weight, m.bias) if isinstance(m, nn.Linear) else m(x)
+    return x
+
+
 class PPO:
     def __init__(self, actor_critic, num_learning_epochs=1, num_mini_batches=1, clip_param=0.2, gamma=0.998, lam=0.95,
                  value_loss_coef=1.0, entropy_coef=0.0, learning_rate=1e-3, max_grad_norm=1.0,
@@ -143,6 +174,7 @@ class PPO:
         # ... and gradient clipping, the adaptive-KL learning-rate rule and Adam are two launches (lg_adam_step) instead of ~60
         # small torch kernels, updating torch.optim.Adam's own state tensors in place.  LG_PPO_ADAM_KERNEL=0 disables.
         self._adam_kernel = self._fused_loss and _os.environ.get("LG_PPO_ADAM_KERNEL", "1") != "0"
+        self._split_k = _os.environ.get("LG_PPO_SPLIT_K", "1") != "0"       # torch MLP path (wide networks): see _LinearSplitK
         self._lib = None
         self.desired_kl, self.schedule, self.learning_rate = desired_kl, schedule, learning_rate
         self.actor_critic = actor_critic.to(device)
@@ -296,8 +328,10 @@ class PPO:
             obs_all = st.observations.flatten(0, 1)
             obs = obs_all[ix]
             cobs = st.privileged_observations.flatten(0, 1)[ix] if st.privileged_observations is not None else obs
-            mu = ac.actor(obs)
-            val = ac.critic(cobs)
+            if self._split_k and isinstance(ac.actor, nn.Sequential) and isinstance(ac.critic, nn.Sequential):
+                mu, val = _mlp_split_k(ac.actor, obs), _mlp_split_k(ac.critic, cobs)
+            else:
+                mu, val = ac.actor(obs), ac.critic(cobs)
         mb, A = mu.shape
         if getattr(self, "_d_mu", None) is None or self._d_mu.shape != mu.shape:
             self._d_mu, self._d_val = torch.empty_like(mu), torch.empty(mb, 1, device=mu.device)

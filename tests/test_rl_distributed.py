@@ -63,3 +63,19 @@ def test_world2_matches_single_process(tmp_path):
     want = alg.storage.advantages
     got = torch.cat((r0["adv"], r1["adv"]), dim=1)
     assert torch.allclose(got, want, atol=1e-5)              # global normalisation via the all-gather
+
+
+def test_split_k_linear_has_the_gradients_of_nn_linear():
+    """rl/ppo.py:_LinearSplitK (the weight gradient as a batched GEMM over row chunks) == nn.Linear under autograd."""
+    import torch.nn as nn
+    from legged_games_gym_amd.rl.ppo import _mlp_split_k
+    torch.manual_seed(0)
+    net = nn.Sequential(nn.Linear(37, 64), nn.ELU(), nn.Linear(64, 32), nn.ELU(), nn.Linear(32, 5)).double()
+    for M in (4096, 777):                                  # 16 chunks / no divisor -> single GEMM
+        x = torch.randn(M, 37, dtype=torch.float64)
+        dy = torch.randn(M, 5, dtype=torch.float64)
+        net.zero_grad(); net(x).backward(dy)
+        want = [p.grad.clone() for p in net.parameters()]
+        net.zero_grad(); _mlp_split_k(net, x).backward(dy)
+        for w, p in zip(want, net.parameters()):
+            assert torch.allclose(w, p.grad, rtol=1e-10, atol=1e-12)
