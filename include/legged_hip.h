@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LG_ABI_VERSION        16
+#define LG_ABI_VERSION        17
 
 #define LG_MAX_LIMBS          4
 #define LG_MAX_CHAIN          6
@@ -249,6 +249,25 @@ int  lg_mlp_forward(const lg_mlp_net *nets, int32_t n_nets, const int64_t *rows,
 size_t lg_mlp_workspace_bytes(const lg_mlp_net *nets, int32_t n_nets);
 int  lg_mlp_backward(const lg_mlp_net *nets, int32_t n_nets, const int64_t *rows, int32_t mb, float *workspace, size_t workspace_bytes,
                      void *stream);
+
+/* What one PPO mini-batch step reads besides the observations (rsl_rl PPO.update [EXTERNAL]; hyper-parameters
+ * legged_robot_config.py:215-228): the rollout storage (flattened [B, .] device arrays, gathered through `rows`), the policy's std
+ * parameter and the loss coefficients; and what it produces besides the network gradients. */
+typedef struct lg_ppo_batch {
+    const float *actions, *old_log_prob, *old_mu, *old_sigma;    /* [B, A], [B], [B, A], [B, A] */
+    const float *advantages, *old_values, *returns;              /* [B] */
+    const float *std;                                            /* [A] */
+    float        clip, value_coef, entropy_coef;
+    int32_t      use_clipped_value;
+    float       *d_std;                                          /* out [A]: dL/dstd */
+    float       *stats;                                          /* out [4]: surrogate mean, value-loss mean, KL mean, entropy */
+} lg_ppo_batch;
+/* lg_mlp_forward + lg_ppo_loss + lg_mlp_backward in ONE pass over the mini-batch: nets[0] = actor, nets[1] = critic (one output).
+ * The networks' outputs never leave the kernel: after the forward pass of a 16-row tile the loss gradient w.r.t. mu / value is
+ * evaluated in registers and fed to the backward pass.  Writes every weight / bias gradient, d_std and stats; `output` and
+ * `grad_output` of the nets are not used.  Same loss expressions and same results as the three separate calls (tests). */
+int  lg_ppo_minibatch(const lg_mlp_net *nets, const int64_t *rows, int32_t mb, const lg_ppo_batch *batch, float *workspace,
+                      size_t workspace_bytes, void *stream);
 
 /* Diagnostic (tools/mlp_probe.py): while `buf` (device, uint64[60]) is set, lg_mlp_forward / lg_mlp_backward launches write the
  * s_memtime stamps of their phases as seen by thread 0 of workgroup (0, 0); NULL stops. */

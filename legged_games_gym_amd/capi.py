@@ -16,7 +16,7 @@ from typing import Dict, Optional
 
 import numpy as np
 
-LG_ABI_VERSION = 16
+LG_ABI_VERSION = 17
 LG_ADAM_SCRATCH_FLOATS = 2050
 LG_MAX_LIMBS, LG_MAX_CHAIN, LG_MAX_DOF = 4, 6, 12
 LG_MAX_LIMB_POINTS, LG_MAX_BASE_POINTS, LG_MAX_BODIES = 8, 4, 20
@@ -181,6 +181,13 @@ class lg_mlp_net(C.Structure):
                 ("input", C.c_void_p), ("output", C.c_void_p), ("grad_output", C.c_void_p), ("dims", i32 * 5)]
 
 
+class lg_ppo_batch(C.Structure):
+    """include/legged_hip.h: lg_ppo_batch."""
+    _fields_ = [(n, C.c_void_p) for n in ("actions", "old_log_prob", "old_mu", "old_sigma", "advantages", "old_values", "returns", "std")] + \
+               [("clip", C.c_float), ("value_coef", C.c_float), ("entropy_coef", C.c_float), ("use_clipped_value", i32),
+                ("d_std", C.c_void_p), ("stats", C.c_void_p)]
+
+
 class lg_rollout_step(C.Structure):
     """include/legged_hip.h: lg_rollout_step."""
     _fields_ = [(n, C.c_void_p) for n in ("obs", "actions", "mean", "rewards", "dones", "time_outs", "storage_obs", "storage_actions",
@@ -250,6 +257,8 @@ def bind_prototypes(lib, prefix: str):
         lib.lg_mlp_workspace_bytes.restype = C.c_size_t
         lib.lg_mlp_backward.argtypes = [C.POINTER(lg_mlp_net), i32, vp, i32, vp, C.c_size_t, vp]
         lib.lg_mlp_backward.restype = C.c_int
+        lib.lg_ppo_minibatch.argtypes = [C.POINTER(lg_mlp_net), vp, i32, C.POINTER(lg_ppo_batch), vp, C.c_size_t, vp]
+        lib.lg_ppo_minibatch.restype = C.c_int
         lib.lg_adam_step.argtypes = [C.POINTER(lg_adam_tensor), i32, vp, C.c_float, C.c_float, C.c_float, C.c_float, vp, C.c_float, vp, vp]
         lib.lg_adam_step.restype = C.c_int
         lib.lg_rollout_record.argtypes = [C.POINTER(lg_rollout_step), vp]
@@ -269,7 +278,7 @@ EXPORTED_SYMBOLS = ["lg_create", "lg_destroy", "lg_bind", "lg_step", "lg_reset_i
                     "lg_physics_substep", "lg_compute_observations_only", "lg_set_params", "lg_last_error",
                     "lg_abi_version", "lg_sizeof", "lg_set_obs_buffer", "lg_policy_create", "lg_policy_destroy", "lg_policy_act",
                     "lg_step_policy", "lg_gae_returns", "lg_ppo_loss", "lg_policy_load_device", "lg_mlp_forward",
-                    "lg_mlp_workspace_bytes", "lg_mlp_backward", "lg_adam_step", "lg_rollout_record", "lg_mlp_trace"]
+                    "lg_mlp_workspace_bytes", "lg_mlp_backward", "lg_adam_step", "lg_rollout_record", "lg_mlp_trace", "lg_ppo_minibatch"]
 
 
 def load_library():

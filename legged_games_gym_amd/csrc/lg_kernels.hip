@@ -1497,7 +1497,7 @@ static int mlp_fill(const lg_mlp_net *nets, int32_t n_nets, const int64_t *rows,
             d.w[l] = s.weights[l]; d.b[l] = s.biases[l];
             gf += s.dims[l + 1] * s.dims[l] + s.dims[l + 1];
         }
-        d.x = s.input; d.y = s.output; d.dy = s.grad_output; d.grad_floats = gf;
+        d.x = s.input; d.y = s.output; d.dy = s.grad_output; d.grad_floats = gf; d.part_stride = gf + LG_PPO_EXTRA;
         memcpy(d.dims, s.dims, sizeof d.dims);
     }
     return 0;
@@ -1529,13 +1529,14 @@ size_t lg_mlp_workspace_bytes(const lg_mlp_net *nets, int32_t n_nets) {
     for (int n = 0; n < n_nets; n++) {
         size_t gf = 0;
         for (int l = 0; l < 4; l++) gf += (size_t)nets[n].dims[l + 1] * nets[n].dims[l] + nets[n].dims[l + 1];
-        total += gf * LG_TRAIN_WGS * sizeof(float);
+        total += (gf + LG_PPO_EXTRA) * LG_TRAIN_WGS * sizeof(float);
     }
     return total;
 }
 
-int lg_mlp_backward(const lg_mlp_net *nets, int32_t n_nets, const int64_t *rows, int32_t mb, float *workspace, size_t workspace_bytes,
-                    void *stream) {
+// shared by lg_mlp_backward (batch == null: dL/dy from nets[n].grad_output) and lg_ppo_minibatch (dL/dy from the fused PPO loss)
+static int mlp_backward_launch(const lg_mlp_net *nets, int32_t n_nets, const int64_t *rows, int32_t mb, const lg_ppo_batch *batch,
+                               float *workspace, size_t workspace_bytes, void *stream) {
     lg::MlpArgs a; int wgs;
     if (int rc = mlp_fill(nets, n_nets, rows, mb, a, wgs, LG_BWD_SLOTS, true)) return rc;
     if (!workspace || workspace_bytes < lg_mlp_workspace_bytes(nets, n_nets)) return fail(-1, "workspace too small (lg_mlp_workspace_bytes)");
@@ -1543,9 +1544,10 @@ int lg_mlp_backward(const lg_mlp_net *nets, int32_t n_nets, const int64_t *rows,
     float *ws = workspace;
     int max_gf = 0;
     for (int n = 0; n < n_nets; n++) {
-        if (!nets[n].grad_output) return fail(-1, "null grad_output");
-        a.net[n].partial = ws; r.partial[n] = ws; ws += (size_t)a.net[n].grad_floats * LG_TRAIN_WGS;
-        r.grad_floats[n] = a.net[n].grad_floats; if (a.net[n].grad_floats > max_gf) max_gf = a.net[n].grad_floats;
+        if (!batch && !nets[n].grad_output) return fail(-1, "null grad_output");
+        a.net[n].partial = ws; r.partial[n] = ws; ws += (size_t)a.net[n].part_stride * LG_TRAIN_WGS;
+        r.grad_floats[n] = a.net[n].grad_floats; r.part_stride[n] = a.net[n].part_stride;
+        if (a.net[n].grad_floats > max_gf) max_gf = a.net[n].grad_floats;
         memcpy(r.dims[n], nets[n].dims, sizeof r.dims[n]);
         for (int l = 0; l < 4; l++) {
             if (!nets[n].grad_weights[l] || !nets[n].grad_biases[l]) return fail(-1, "null gradient pointer");
@@ -1553,18 +1555,39 @@ int lg_mlp_backward(const lg_mlp_net *nets, int32_t n_nets, const int64_t *rows,
         }
     }
     r.n_partials = wgs * LG_BWD_SLOTS;
+    if (batch) {
+        if (n_nets != 2 || nets[1].dims[4] != 1) return fail(-1, "lg_ppo_minibatch needs nets = {actor, critic (one output)}");
+        if (!rows || !batch->actions || !batch->old_log_prob || !batch->old_mu || !batch->old_sigma || !batch->advantages || !batch->old_values ||
+            !batch->returns || !batch->std || !batch->d_std || !batch->stats) return fail(-1, "null PPO batch pointer");
+        a.ppo = lg::PpoArgs{batch->actions, batch->old_log_prob, batch->old_mu, batch->old_sigma, batch->advantages, batch->old_values, batch->returns,
+                            batch->std, batch->clip, batch->value_coef, 1.0f / (float)mb, batch->use_clipped_value};
+        r.loss = 1; r.num_actions = nets[0].dims[4]; r.std = batch->std; r.ecoef = batch->entropy_coef; r.d_std = batch->d_std; r.stats = batch->stats;
+    }
     hipStream_t st = (hipStream_t)stream;
     constexpr size_t lds_bytes = lg::TrainLds<3, 8, 4, 2, true, LG_BWD_SLOTS>::floats * sizeof(float);
     static_assert(lds_bytes <= 160 * 1024, "k_mlp_train backward exceeds the CU's LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void *)lg::k_mlp_train<3, 8, 4, 2, true, LG_BWD_SLOTS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        HIP_TRY(hipFuncSetAttribute((const void *)lg::k_mlp_train<3, 8, 4, 2, true, LG_BWD_SLOTS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        HIP_TRY(hipFuncSetAttribute((const void *)lg::k_mlp_train<3, 8, 4, 2, true, LG_BWD_SLOTS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         attr_set = true;
     }
-    hipLaunchKernelGGL((lg::k_mlp_train<3, 8, 4, 2, true, LG_BWD_SLOTS>), dim3(wgs, n_nets), dim3(64 * LG_TRAIN_WAVES * LG_BWD_SLOTS), lds_bytes, st, a);
-    hipLaunchKernelGGL(lg::k_mlp_reduce, dim3((max_gf + 31) / 32, n_nets), dim3(256), 0, st, r);
+    if (batch) hipLaunchKernelGGL((lg::k_mlp_train<3, 8, 4, 2, true, LG_BWD_SLOTS, true>), dim3(wgs, n_nets), dim3(64 * LG_TRAIN_WAVES * LG_BWD_SLOTS), lds_bytes, st, a);
+    else hipLaunchKernelGGL((lg::k_mlp_train<3, 8, 4, 2, true, LG_BWD_SLOTS, false>), dim3(wgs, n_nets), dim3(64 * LG_TRAIN_WAVES * LG_BWD_SLOTS), lds_bytes, st, a);
+    hipLaunchKernelGGL(lg::k_mlp_reduce, dim3((max_gf + (batch ? LG_PPO_EXTRA : 0) + 31) / 32, n_nets), dim3(256), 0, st, r);
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+int lg_mlp_backward(const lg_mlp_net *nets, int32_t n_nets, const int64_t *rows, int32_t mb, float *workspace, size_t workspace_bytes,
+                    void *stream) {
+    return mlp_backward_launch(nets, n_nets, rows, mb, nullptr, workspace, workspace_bytes, stream);
+}
+
+int lg_ppo_minibatch(const lg_mlp_net *nets, const int64_t *rows, int32_t mb, const lg_ppo_batch *batch, float *workspace,
+                     size_t workspace_bytes, void *stream) {
+    if (!batch) return fail(-1, "null batch");
+    return mlp_backward_launch(nets, 2, rows, mb, batch, workspace, workspace_bytes, stream);
 }
 
 int lg_rollout_record(const lg_rollout_step *s, void *stream) {

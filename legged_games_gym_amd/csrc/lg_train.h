@@ -30,14 +30,24 @@ struct MlpNetArgs {
     const float *x;                    // [R, dims[0]] input rows
     float *y;                          // forward: [mb, dims[4]]
     const float *dy;                   // backward: [mb, dims[4]]
-    float *partial;                    // backward: [workgroups][grad_floats] per-workgroup partial sums
+    float *partial;                    // backward: [groups][part_stride] per-group partial sums (gradients, then LG_PPO_EXTRA loss terms)
     int32_t dims[5];
     int32_t grad_floats;               // sum over layers of out*in + out
+    int32_t part_stride;
+};
+// PPO loss terms of rsl_rl PPO.update ([EXTERNAL]; same expressions as k_ppo_loss), evaluated inside the backward kernel
+#define LG_PPO_EXTRA 20                // per-group partials after the gradients: d_std[16], then sums of {surrogate, value loss, KL, -}
+struct PpoArgs {
+    const float *actions, *old_lp, *old_mu, *old_sigma, *adv, *old_values, *returns;   // rollout storage, indexed by rows[i]
+    const float *std;                  // [A] policy std parameter
+    float clip, vcoef, inv_n;
+    int32_t clipped_value;
 };
 struct MlpArgs {
     MlpNetArgs net[2];
     const int64_t *rows;               // [mb] row indices into x, or null for 0..mb-1
     int32_t mb, n_tiles;
+    PpoArgs ppo;                       // LOSS build only
     unsigned long long *trace;         // diagnostic: s_memtime stamps of workgroup (0, 0), thread 0 (lg_mlp_trace); null in normal use
 };
 
@@ -228,8 +238,10 @@ template <int D0T, int D1T, int D2T, int D3T, bool BWD, int SLOTS> struct TrainL
 // One persistent workgroup per (slice blockIdx.x, net blockIdx.y): weights -> LDS once, then it walks its row tiles.  SLOTS
 // groups of LG_TRAIN_WAVES waves each work on their own row tile (own activation area, shared weights): with several waves
 // per SIMD one group's MFMAs overlap another's LDS traffic and ELUs.  All groups run the same barrier sequence.
-template <int D0T, int D1T, int D2T, int D3T, bool BWD, int SLOTS>
+// LOSS (with BWD): net 0 is the actor, net 1 the critic; dL/dy is not read but computed from the PPO loss after the forward pass.
+template <int D0T, int D1T, int D2T, int D3T, bool BWD, int SLOTS, bool LOSS = false>
 __global__ void __launch_bounds__(64 * LG_TRAIN_WAVES * SLOTS) k_mlp_train(const MlpArgs A) {
+    static_assert(!LOSS || BWD, "the fused loss feeds the backward pass");
     using S = TrainLds<D0T, D1T, D2T, D3T, BWD, SLOTS>;
     constexpr int X0 = 0, X1 = D0T, X2 = D0T + D1T, X3 = D0T + D1T + D2T;        // activation tile offsets
     constexpr int G1 = 0, G2 = D1T, G3 = D1T + D2T, G4 = D1T + D2T + D3T;        // gradient tiles w.r.t. x1, x2, x3 pre-acts, and y
@@ -266,6 +278,16 @@ __global__ void __launch_bounds__(64 * LG_TRAIN_WAVES * SLOTS) k_mlp_train(const
     static_assert(D0T <= LG_TRAIN_WAVES, "one input tile per wave");
     float4 xv_next = make_float4(0.f, 0.f, 0.f, 0.f), dy_next = make_float4(0.f, 0.f, 0.f, 0.f);
     int64_t src_next = 0;                                          // storage row of this lane in the tile requested NEXT
+    // LOSS: the last role of each group evaluates the loss; its per-row inputs are gathered with the rows, one tile ahead
+    const bool actor = blockIdx.y == 0;
+    float4 act_next = dy_next, omu_next = dy_next, osg_next = dy_next;
+    float s0_next = 0.f, s1_next = 0.f;                            // actor: old log-prob, advantage; critic: old value, return
+    float gstd[4] = {0.f, 0.f, 0.f, 0.f}, sum_sur = 0.f, sum_kl = 0.f, sum_val = 0.f;
+    float sg[4] = {1.f, 1.f, 1.f, 1.f}, isg[4] = {1.f, 1.f, 1.f, 1.f}, lsg[4] = {0.f, 0.f, 0.f, 0.f};
+    if (LOSS && actor && wave == LG_TRAIN_WAVES - 1) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) if (4 * g + c < d4) { sg[c] = A.ppo.std[4 * g + c]; isg[c] = 1.0f / sg[c]; lsg[c] = __logf(sg[c]); }
+    }
     const bool vec_in = (d0 & 3) == 0;
     auto row_index = [&](int rt) -> int64_t {                      // rows past the batch re-read the last row (their dL/dy is zero)
         const int r = min(rt * 16 + (lane & 15), A.mb - 1);
@@ -278,12 +300,25 @@ __global__ void __launch_bounds__(64 * LG_TRAIN_WAVES * SLOTS) k_mlp_train(const
             if (vec_in && k + 3 < d0) xv_next = *reinterpret_cast<const float4 *>(xr);
             else xv_next = make_float4(k < d0 ? xr[0] : 0.f, k + 1 < d0 ? xr[1] : 0.f, k + 2 < d0 ? xr[2] : 0.f, k + 3 < d0 ? xr[3] : 0.f);
         }
-        if (BWD && wave == LG_TRAIN_WAVES - 1) {                   // dL/dy tile (zero for rows past the batch: they contribute nothing)
+        if (BWD && !LOSS && wave == LG_TRAIN_WAVES - 1) {          // dL/dy tile (zero for rows past the batch: they contribute nothing)
             const int r = rt * 16 + (lane & 15);
             float v[4];
 #pragma unroll
             for (int c = 0; c < 4; c++) { const int k = 4 * g + c; v[c] = (r < A.mb && k < d4) ? N.dy[(size_t)r * d4 + k] : 0.0f; }
             dy_next = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        if (LOSS && wave == LG_TRAIN_WAVES - 1) {
+            if (actor) {
+                const size_t o = (size_t)src * d4 + 4 * g;
+                auto quad = [&](const float *p) {
+                    return ((d4 & 3) == 0 && 4 * g + 3 < d4) ? *reinterpret_cast<const float4 *>(p + o)
+                         : make_float4(4 * g < d4 ? p[o] : 0.f, 4 * g + 1 < d4 ? p[o + 1] : 0.f, 4 * g + 2 < d4 ? p[o + 2] : 0.f, 4 * g + 3 < d4 ? p[o + 3] : 0.f);
+                };
+                act_next = quad(A.ppo.actions); omu_next = quad(A.ppo.old_mu); osg_next = quad(A.ppo.old_sigma);
+                s0_next = A.ppo.old_lp[src]; s1_next = A.ppo.adv[src];
+            } else {
+                s0_next = A.ppo.old_values[src]; s1_next = A.ppo.returns[src];
+            }
         }
     };
     const int stride = gridDim.x * SLOTS, n_iter = (A.n_tiles + stride - 1) / stride;     // uniform trip count: barriers inside
@@ -306,6 +341,8 @@ __global__ void __launch_bounds__(64 * LG_TRAIN_WAVES * SLOTS) k_mlp_train(const
         const int r = rt * 16 + (lane & 15);
         const bool live = active && r < A.mb;
         const float4 dyv = active ? dy_next : make_float4(0.f, 0.f, 0.f, 0.f);   // an idle group still runs the barriers; it adds zeros
+        const float4 actv = act_next, omuv = omu_next, osgv = osg_next;
+        const float s0v = s0_next, s1v = s1_next;
         if (wave < D0T) {
             if (BWD) tile_store_t(xT + X0, wave, lane, xv_next); else x[X0 + wave][lane] = xv_next;
         }
@@ -327,10 +364,73 @@ __global__ void __launch_bounds__(64 * LG_TRAIN_WAVES * SLOTS) k_mlp_train(const
         LG_TR();
         if (BWD) train_forward_layer_t<D2T, D3T>(wl2, xT + X2, xT + X3, wave, lane);
         else train_forward_layer<D2T, D3T, true>(wl2, x + X2, x + X3, wave, lane);
-        if (BWD && wave == LG_TRAIN_WAVES - 1) tile_store_t(gT + G4, 0, lane, dyv);
+        if (BWD && !LOSS && wave == LG_TRAIN_WAVES - 1) tile_store_t(gT + G4, 0, lane, dyv);
         LG_TR();
         __syncthreads();
         LG_TR();
+        if (LOSS) {
+            if (wave == LG_TRAIN_WAVES - 1) {
+                // output layer in registers: lane (row l&15, group g) holds y[4g + c]
+                using L3 = LdsLayer<D3T, 1>;
+                const float4 bv = *reinterpret_cast<const float4 *>(wl3 + L3::w_floats + 4 * g);
+                f32x4 y = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+                for (int t = 0; t < D3T; t++) {
+                    const float4 wv = *reinterpret_cast<const float4 *>(wl3 + (lane & 15) * L3::stride + 16 * t + 4 * g);
+                    const float4 xv = tile_load_b(xT + X3, t, lane);
+                    y = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.x, xv.x, y, 0, 0, 0);
+                    y = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.y, xv.y, y, 0, 0, 0);
+                    y = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.z, xv.z, y, 0, 0, 0);
+                    y = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.w, xv.w, y, 0, 0, 0);
+                }
+                const PpoArgs &P = A.ppo;
+                float d[4] = {0.f, 0.f, 0.f, 0.f};
+                if (actor) {
+                    const float av[4] = {actv.x, actv.y, actv.z, actv.w}, om[4] = {omuv.x, omuv.y, omuv.z, omuv.w}, os[4] = {osgv.x, osgv.y, osgv.z, osgv.w};
+                    float z[4], lp = 0.0f, kl = 0.0f;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        z[c] = 0.0f;
+                        if (4 * g + c < d4) {
+                            z[c] = (av[c] - y[c]) * isg[c];
+                            lp += -0.5f * z[c] * z[c] - lsg[c] - 0.918938533f;                     // log N(a; mu, sigma)
+                            kl += __logf(sg[c] / os[c] + 1.0e-5f) + (os[c] * os[c] + (om[c] - y[c]) * (om[c] - y[c])) * (0.5f * isg[c] * isg[c]) - 0.5f;
+                        }
+                    }
+                    lp += __shfl_xor(lp, 16); lp += __shfl_xor(lp, 32);                            // the row's actions live in 4 lanes
+                    kl += __shfl_xor(kl, 16); kl += __shfl_xor(kl, 32);
+                    const float ad = s1v, ratio = __expf(lp - s0v);
+                    const float t1 = -ad * ratio, t2 = -ad * fminf(fmaxf(ratio, 1.0f - P.clip), 1.0f + P.clip);
+                    const bool inside = ratio >= 1.0f - P.clip && ratio <= 1.0f + P.clip;
+                    const float dlp = (t1 > t2 || inside) ? -ad * ratio : (t1 == t2 ? -0.5f * ad * ratio : 0.0f);
+                    if (live) {
+#pragma unroll
+                        for (int c = 0; c < 4; c++) if (4 * g + c < d4) {
+                            d[c] = P.inv_n * dlp * z[c] * isg[c];                                  // d lp / d mu = (a - mu) / sigma^2
+                            gstd[c] += P.inv_n * dlp * (z[c] * z[c] - 1.0f) * isg[c];              // d lp / d sigma
+                        }
+                        if (g == 0) { sum_sur += fmaxf(t1, t2); sum_kl += kl; }
+                    }
+                } else if (g == 0) {
+                    const float v = y[0], tv = s0v, R = s1v;
+                    float dv, vl;
+                    if (P.clipped_value) {
+                        const float dvt = v - tv, vc = tv + fminf(fmaxf(dvt, -P.clip), P.clip);
+                        const float v1 = (v - R) * (v - R), v2 = (vc - R) * (vc - R);
+                        const bool in_v = dvt >= -P.clip && dvt <= P.clip;
+                        vl = fmaxf(v1, v2);
+                        dv = (v1 > v2 || in_v) ? 2.0f * (v - R) : (v1 == v2 ? (v - R) : 0.0f);
+                    } else {
+                        vl = (R - v) * (R - v);
+                        dv = 2.0f * (v - R);
+                    }
+                    if (live) { d[0] = P.vcoef * P.inv_n * dv; sum_val += vl; }
+                }
+                tile_store_t(gT + G4, 0, lane, make_float4(d[0], d[1], d[2], d[3]));
+            }
+            LG_TR();
+            __syncthreads();
+        }
         if (!BWD) {
             if (wave == 0) {
                 // the output layer reuses x tile X0 as scratch (its inputs are no longer needed in forward-only mode)
@@ -363,8 +463,22 @@ __global__ void __launch_bounds__(64 * LG_TRAIN_WAVES * SLOTS) k_mlp_train(const
         __syncthreads();
         LG_TR();
     }
+    if (LOSS && wave == LG_TRAIN_WAVES - 1) {                      // per-group loss partials: d_std[16] | surrogate, value loss, KL sums
+        float *ex = N.partial + (size_t)(blockIdx.x * SLOTS + slot) * N.part_stride + N.grad_floats;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) gstd[c] += __shfl_xor(gstd[c], o);
+            sum_sur += __shfl_xor(sum_sur, o); sum_kl += __shfl_xor(sum_kl, o); sum_val += __shfl_xor(sum_val, o);
+        }
+        if ((lane & 15) == 0) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) ex[4 * g + c] = gstd[c];
+            if (g == 0) { ex[16] = sum_sur * A.ppo.inv_n; ex[17] = sum_val * A.ppo.inv_n; ex[18] = sum_kl * A.ppo.inv_n; ex[19] = 0.0f; }
+        }
+    }
     if (BWD) {
-        float *part = N.partial + (size_t)(blockIdx.x * SLOTS + slot) * N.grad_floats;
+        float *part = N.partial + (size_t)(blockIdx.x * SLOTS + slot) * N.part_stride;
         train_flush<D0T, D1T>(a0, part, d0, d1, wave, lane); part += (size_t)d1 * d0 + d1;
         train_flush<D1T, D2T>(a1, part, d1, d2, wave, lane); part += (size_t)d2 * d1 + d2;
         train_flush<D2T, D3T>(a2, part, d2, d3, wave, lane); part += (size_t)d3 * d2 + d3;
@@ -378,8 +492,13 @@ struct MlpReduceArgs {
     const float *partial[2];
     float *gw[2][4], *gb[2][4];
     int32_t dims[2][5];
-    int32_t grad_floats[2];
+    int32_t grad_floats[2], part_stride[2];
     int32_t n_partials;
+    // fused-loss launches: the LG_PPO_EXTRA partials behind the gradients become d_std [A] (+ entropy term) and stats[4]
+    int32_t loss, num_actions;
+    const float *std;
+    float ecoef;
+    float *d_std, *stats;
 };
 // grads = sum over workgroups of the partials, in a fixed order.  A workgroup owns 32 consecutive gradient elements; its 8
 // slices (threadIdx >> 5) sum partials k = slice, slice + 8, ... (128-byte coalesced rows) and meet in LDS.
@@ -387,13 +506,13 @@ __global__ void __launch_bounds__(256) k_mlp_reduce(const MlpReduceArgs A) {
     __shared__ float red[8][32];
     const int n = blockIdx.y, e = threadIdx.x & 31, slice = threadIdx.x >> 5;
     const int j = blockIdx.x * 32 + e;
-    const int gf = A.grad_floats[n];
-    const bool ok = j < gf;
+    const int gf = A.grad_floats[n], ps = A.part_stride[n];
+    const bool ok = j < gf + (A.loss ? LG_PPO_EXTRA : 0);
     const float *p = A.partial[n] + (ok ? j : 0);
     float s0 = 0.f, s1 = 0.f;
     int k = slice;
-    for (; k + 8 < A.n_partials; k += 16) { s0 += p[(size_t)k * gf]; s1 += p[(size_t)(k + 8) * gf]; }
-    if (k < A.n_partials) s0 += p[(size_t)k * gf];
+    for (; k + 8 < A.n_partials; k += 16) { s0 += p[(size_t)k * ps]; s1 += p[(size_t)(k + 8) * ps]; }
+    if (k < A.n_partials) s0 += p[(size_t)k * ps];
     red[slice][e] = s0 + s1;
     __syncthreads();
     if (slice != 0 || !ok) return;
@@ -407,6 +526,17 @@ __global__ void __launch_bounds__(256) k_mlp_reduce(const MlpReduceArgs A) {
         if (off < nb) { A.gb[n][l][off] = s; return; }
         off -= nb;
     }
+    // off = index into the loss partials (fused-loss launches only)
+    if (n == 0) {
+        if (off < 16) { if (off < A.num_actions) A.d_std[off] = s - A.ecoef / A.std[off]; }       // + d(-ecoef * entropy) / d sigma
+        else if (off == 16) A.stats[0] = s;
+        else if (off == 18) A.stats[2] = s;
+        else if (off == 19) {                          // entropy is row-independent: sum_a (0.5 + 0.5 log 2 pi + log sigma_a)
+            float H = 0.0f;
+            for (int a = 0; a < A.num_actions; a++) H += 1.418938533f + __logf(A.std[a]);
+            A.stats[3] = H;
+        }
+    } else if (off == 17) A.stats[1] = s;
 }
 
 // ---- gradient-norm clip + Adam + adaptive-KL learning rate: the rest of a PPO mini-batch step in three launches ---------------

@@ -77,3 +77,9 @@ class MlpTrainer:
         self._check(self.lib.lg_mlp_backward(self.desc, len(self.nets), rows.data_ptr() if rows is not None else None, self.mb,
                                              self.workspace.data_ptr(), self.workspace.numel() * 4,
                                              torch.cuda.current_stream(dev).cuda_stream), "lg_mlp_backward")
+
+    def ppo_minibatch(self, rows: torch.Tensor, batch: "capi.lg_ppo_batch"):
+        """Forward, PPO loss and backward in one pass (lg_ppo_minibatch): nets = [actor, critic]; fills every .grad, batch.d_std, batch.stats."""
+        dev = self.inputs[0].device
+        self._check(self.lib.lg_ppo_minibatch(self.desc, rows.data_ptr(), self.mb, C.byref(batch), self.workspace.data_ptr(),
+                                              self.workspace.numel() * 4, torch.cuda.current_stream(dev).cuda_stream), "lg_ppo_minibatch")

@@ -174,6 +174,7 @@ class PPO:
         # ... and gradient clipping, the adaptive-KL learning-rate rule and Adam are two launches (lg_adam_step) instead of ~60
         # small torch kernels, updating torch.optim.Adam's own state tensors in place.  LG_PPO_ADAM_KERNEL=0 disables.
         self._adam_kernel = self._fused_loss and _os.environ.get("LG_PPO_ADAM_KERNEL", "1") != "0"
+        self._fused_minibatch = _os.environ.get("LG_PPO_FUSED_MINIBATCH", "1") != "0"   # lg_ppo_minibatch instead of forward / loss / backward
         self._split_k = _os.environ.get("LG_PPO_SPLIT_K", "1") != "0"       # torch MLP path (wide networks): see _LinearSplitK
         self._lib = None
         self.desired_kl, self.schedule, self.learning_rate = desired_kl, schedule, learning_rate
@@ -316,11 +317,9 @@ class PPO:
             self._adam_scratch = torch.zeros(capi.LG_ADAM_SCRATCH_FLOATS, device=self.device)
         return table
 
-    def _mb_step_fused(self):
-        """Mini-batch step with the fused loss kernel: MLP forward -> lg_ppo_loss -> MLP backward -> clip -> Adam.  The MLP
-        passes are the MFMA learner kernels when the networks have their shape, torch (autograd) otherwise."""
+    def _mb_forward_loss_backward(self, tr):
+        """MLP forward -> lg_ppo_loss -> MLP backward as separate launches (learner kernels when ``tr`` is given, torch otherwise)."""
         st, ac, ix = self.storage, self.actor_critic, self._ix
-        tr = self._mlp_trainer()
         if tr is not None:
             tr.refresh()                             # parameter / .grad addresses (stable in steady state)
             mu, val = tr.forward(ix)
@@ -348,6 +347,29 @@ class PPO:
             tr.backward(ix)
         else:
             torch.autograd.backward([mu, val], [d_mu, d_val])
+
+    def _mb_step_fused(self):
+        """Mini-batch step on the device kernels: [MLP forward -> PPO loss -> MLP backward] -> gradient clip + KL rule + Adam.
+        The bracket is ONE kernel (lg_ppo_minibatch) when the networks have the learner kernels' shape; otherwise torch MLP
+        passes (autograd) around lg_ppo_loss."""
+        st, ac, ix = self.storage, self.actor_critic, self._ix
+        tr = self._mlp_trainer()
+        p = lambda t: t.data_ptr()
+        if tr is not None and self._fused_minibatch:
+            # forward + loss + backward of both networks in ONE kernel (lg_ppo_minibatch): mu / value never reach HBM
+            mb, A = ix.numel(), ac.std.numel()
+            if getattr(self, "_d_std", None) is None or self._d_std.numel() != A:
+                self._d_std, self._stats = torch.zeros(A, device=self.device), torch.zeros(4, device=self.device)
+            tr.refresh()
+            from .. import capi
+            b = capi.lg_ppo_batch()
+            b.actions, b.old_log_prob, b.old_mu, b.old_sigma = p(st.actions), p(st.actions_log_prob), p(st.mu), p(st.sigma)
+            b.advantages, b.old_values, b.returns, b.std = p(st.advantages), p(st.values), p(st.returns), p(ac.std)
+            b.clip, b.value_coef, b.entropy_coef = float(self.clip_param), float(self.value_loss_coef), float(self.entropy_coef)
+            b.use_clipped_value, b.d_std, b.stats = int(bool(self.use_clipped_value_loss)), p(self._d_std), p(self._stats)
+            tr.ppo_minibatch(ix, b)
+        else:
+            self._mb_forward_loss_backward(tr)
         ac.std.grad = self._d_std
         adaptive = self.desired_kl is not None and self.schedule == "adaptive"
         if _world() > 1:                             # data-parallel ranks: mean gradient and mean KL (rollout shards are equal-sized)
@@ -361,7 +383,7 @@ class PPO:
             rc = self._lib.lg_adam_step(table, len(table), p(self._lr), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
                                         float(self.max_grad_norm), p(self._stats[2:]) if adaptive else None,
                                         float(self.desired_kl) if adaptive else 0.0, p(self._adam_scratch),
-                                        torch.cuda.current_stream(mu.device).cuda_stream)
+                                        torch.cuda.current_stream(self.device).cuda_stream)
             if rc != 0:
                 raise RuntimeError(f"lg_adam_step failed ({rc}): {self._lib.lg_last_error().decode()}")
         else:
