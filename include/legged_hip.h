@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LG_ABI_VERSION        17
+#define LG_ABI_VERSION        18
 
 #define LG_MAX_LIMBS          4
 #define LG_MAX_CHAIN          6
@@ -261,6 +261,7 @@ typedef struct lg_ppo_batch {
     int32_t      use_clipped_value;
     float       *d_std;                                          /* out [A]: dL/dstd */
     float       *stats;                                          /* out [4]: surrogate mean, value-loss mean, KL mean, entropy */
+    float       *loss_acc;                                       /* optional [2]: += {value-loss mean, surrogate mean} (running sums of an update) */
 } lg_ppo_batch;
 /* lg_mlp_forward + lg_ppo_loss + lg_mlp_backward in ONE pass over the mini-batch: nets[0] = actor, nets[1] = critic (one output).
  * The networks' outputs never leave the kernel: after the forward pass of a 16-row tile the loss gradient w.r.t. mu / value is

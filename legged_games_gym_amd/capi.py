@@ -16,7 +16,7 @@ from typing import Dict, Optional
 
 import numpy as np
 
-LG_ABI_VERSION = 17
+LG_ABI_VERSION = 18
 LG_ADAM_SCRATCH_FLOATS = 2050
 LG_MAX_LIMBS, LG_MAX_CHAIN, LG_MAX_DOF = 4, 6, 12
 LG_MAX_LIMB_POINTS, LG_MAX_BASE_POINTS, LG_MAX_BODIES = 8, 4, 20
@@ -185,7 +185,7 @@ class lg_ppo_batch(C.Structure):
     """include/legged_hip.h: lg_ppo_batch."""
     _fields_ = [(n, C.c_void_p) for n in ("actions", "old_log_prob", "old_mu", "old_sigma", "advantages", "old_values", "returns", "std")] + \
                [("clip", C.c_float), ("value_coef", C.c_float), ("entropy_coef", C.c_float), ("use_clipped_value", i32),
-                ("d_std", C.c_void_p), ("stats", C.c_void_p)]
+                ("d_std", C.c_void_p), ("stats", C.c_void_p), ("loss_acc", C.c_void_p)]
 
 
 class lg_rollout_step(C.Structure):

@@ -1561,7 +1561,7 @@ static int mlp_backward_launch(const lg_mlp_net *nets, int32_t n_nets, const int
             !batch->returns || !batch->std || !batch->d_std || !batch->stats) return fail(-1, "null PPO batch pointer");
         a.ppo = lg::PpoArgs{batch->actions, batch->old_log_prob, batch->old_mu, batch->old_sigma, batch->advantages, batch->old_values, batch->returns,
                             batch->std, batch->clip, batch->value_coef, 1.0f / (float)mb, batch->use_clipped_value};
-        r.loss = 1; r.num_actions = nets[0].dims[4]; r.std = batch->std; r.ecoef = batch->entropy_coef; r.d_std = batch->d_std; r.stats = batch->stats;
+        r.loss = 1; r.num_actions = nets[0].dims[4]; r.std = batch->std; r.ecoef = batch->entropy_coef; r.d_std = batch->d_std; r.stats = batch->stats; r.loss_acc = batch->loss_acc;
     }
     hipStream_t st = (hipStream_t)stream;
     constexpr size_t lds_bytes = lg::TrainLds<3, 8, 4, 2, true, LG_BWD_SLOTS>::floats * sizeof(float);

@@ -499,6 +499,7 @@ struct MlpReduceArgs {
     const float *std;
     float ecoef;
     float *d_std, *stats;
+    float *loss_acc;           // optional [2]: += {value-loss mean, surrogate mean} (the update's running sums for the log)
 };
 // grads = sum over workgroups of the partials, in a fixed order.  A workgroup owns 32 consecutive gradient elements; its 8
 // slices (threadIdx >> 5) sum partials k = slice, slice + 8, ... (128-byte coalesced rows) and meet in LDS.
@@ -529,14 +530,14 @@ __global__ void __launch_bounds__(256) k_mlp_reduce(const MlpReduceArgs A) {
     // off = index into the loss partials (fused-loss launches only)
     if (n == 0) {
         if (off < 16) { if (off < A.num_actions) A.d_std[off] = s - A.ecoef / A.std[off]; }       // + d(-ecoef * entropy) / d sigma
-        else if (off == 16) A.stats[0] = s;
+        else if (off == 16) { A.stats[0] = s; if (A.loss_acc) A.loss_acc[1] += s; }
         else if (off == 18) A.stats[2] = s;
         else if (off == 19) {                          // entropy is row-independent: sum_a (0.5 + 0.5 log 2 pi + log sigma_a)
             float H = 0.0f;
             for (int a = 0; a < A.num_actions; a++) H += 1.418938533f + __logf(A.std[a]);
             A.stats[3] = H;
         }
-    } else if (off == 17) A.stats[1] = s;
+    } else if (off == 17) { A.stats[1] = s; if (A.loss_acc) A.loss_acc[0] += s; }
 }
 
 // ---- gradient-norm clip + Adam + adaptive-KL learning rate: the rest of a PPO mini-batch step in three launches ---------------

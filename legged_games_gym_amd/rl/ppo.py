@@ -367,9 +367,12 @@ class PPO:
             b.advantages, b.old_values, b.returns, b.std = p(st.advantages), p(st.values), p(st.returns), p(ac.std)
             b.clip, b.value_coef, b.entropy_coef = float(self.clip_param), float(self.value_loss_coef), float(self.entropy_coef)
             b.use_clipped_value, b.d_std, b.stats = int(bool(self.use_clipped_value_loss)), p(self._d_std), p(self._stats)
+            b.loss_acc = p(self._acc)                # the kernel also keeps the update's running loss sums
             tr.ppo_minibatch(ix, b)
+            acc_done = True
         else:
             self._mb_forward_loss_backward(tr)
+            acc_done = False
         ac.std.grad = self._d_std
         adaptive = self.desired_kl is not None and self.schedule == "adaptive"
         if _world() > 1:                             # data-parallel ranks: mean gradient and mean KL (rollout shards are equal-sized)
@@ -394,9 +397,10 @@ class PPO:
                     self._lr.copy_(torch.where(kl > self.desired_kl * 2.0, down, torch.where((kl < self.desired_kl / 2.0) & (kl > 0.0), up, lr)))
             nn.utils.clip_grad_norm_(ac.parameters(), self.max_grad_norm)
             self.optimizer.step()
-        with torch.no_grad():
-            self._acc[0] += self._stats[1]
-            self._acc[1] += self._stats[0]
+        if not acc_done:
+            with torch.no_grad():
+                self._acc[0] += self._stats[1]
+                self._acc[1] += self._stats[0]
 
     def _zero_grad(self):
         # the learner kernels overwrite persistent .grad tensors (their addresses are baked into the captured graph)
