@@ -161,7 +161,7 @@ class PPO:
         # Single-GPU runs replay one captured HIP graph per mini-batch step (forward, losses, backward, grad clip, Adam and
         # the adaptive-KL learning rate all on the device): the flat networks' update is launch-bound (~150 tiny kernels).
         self._graph_ok = bool(graphed_update) and str(device).startswith("cuda")
-        self._graph, self._graph_key = None, None
+        self._graph, self._graph_key, self._graph_whole = None, None, False
         self._updates_done = 0
         # ... and the surrogate / value / entropy losses with their gradients w.r.t. the network outputs come from ONE HIP kernel
         # (``lg_ppo_loss``) instead of ~100 small torch kernels; autograd only runs through the two MLPs.
@@ -449,38 +449,65 @@ class PPO:
             # the storage was re-allocated: the captured graph reads the old buffers; warm up eagerly again before re-capturing
             self._graph, self._mlp, self._updates_done = None, None, 0
         self._graph_key = key
-        if self._graph is None and (not hasattr(self, "_ix") or self._ix.numel() != mb):
-            self._ix = torch.zeros(mb, dtype=torch.int64, device=self.device)
+        if self._graph is None and (getattr(self, "_perm_buf", None) is None or self._perm_buf.numel() != self.num_mini_batches * mb):
+            # mini-batch i reads rows _perm_buf[i*mb : (i+1)*mb]: fixed addresses, so captured kernels need no index copies
+            self._perm_buf = torch.zeros(self.num_mini_batches * mb, dtype=torch.int64, device=self.device)
+            self._ix_one = torch.zeros(mb, dtype=torch.int64, device=self.device)      # row list of the one-step graph
+            self._ix = self._ix_one
             self._acc = torch.zeros(2, device=self.device)
         self._acc.zero_()
         # The first update runs eagerly ON THE CAPTURE STREAM: it is the warm-up torch asks for before capturing autograd +
         # optimiser work (library handles / workspaces and the optimiser state get created on that stream, outside capture).
         if self._graph is None and not hasattr(self, "_gstream"):
             self._gstream = torch.cuda.Stream(device=self.device)
-        capture_now = self._graph is None and self._updates_done >= 1
         cur = torch.cuda.current_stream(self.device)
         if perm is None:                             # one permutation per update, re-used by every epoch (rsl_rl)
             perm = torch.randperm(self.num_mini_batches * mb, device=self.device)
-        for _ in range(self.num_learning_epochs):
-            for i in range(self.num_mini_batches):
-                self._ix.copy_(perm[i * mb:(i + 1) * mb])
-                if self._graph is not None:
+        self._perm_buf.copy_(perm[:self._perm_buf.numel()])
+        views = [self._perm_buf[i * mb:(i + 1) * mb] for i in range(self.num_mini_batches)]
+        if self._graph is not None and self._graph_whole:
+            self._graph.replay()                     # the whole update (epochs x mini-batches) is one graph
+        elif self._graph is not None:
+            for _ in range(self.num_learning_epochs):
+                for i in range(self.num_mini_batches):
+                    self._ix_one.copy_(views[i])     # one-step graph (torch MLP path): reads _ix_one
                     self._graph.replay()
-                    continue
-                self._gstream.wait_stream(cur)
-                if capture_now:
-                    self._zero_grad()
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, stream=self._gstream):
-                        self._mb_step()
-                    self._graph = g
-                    capture_now = False
-                    g.replay()                               # the capture did not execute: run this mini-batch now
+        elif self._updates_done >= 1:
+            # Capture.  On the kernel path a mini-batch step is 5 launches, so all epochs x mini-batches go into ONE graph (each
+            # step reading its own slice of _perm_buf); the torch MLP path (~150 launches and fresh activations per step) keeps a
+            # one-step graph replayed 20 times.
+            self._graph_whole = self._mlp is not None and self._fused_minibatch and self._adam_kernel
+            self._gstream.wait_stream(cur)
+            self._zero_grad()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=self._gstream):
+                if self._graph_whole:
+                    for _ in range(self.num_learning_epochs):
+                        for i in range(self.num_mini_batches):
+                            self._ix = views[i]
+                            self._mb_step()
                 else:
+                    self._ix = self._ix_one
+                    self._mb_step()
+            self._graph = g
+            self._ix = self._ix_one
+            if self._graph_whole:
+                g.replay()                           # the capture did not execute
+            else:
+                for _ in range(self.num_learning_epochs):
+                    for i in range(self.num_mini_batches):
+                        self._ix_one.copy_(views[i])
+                        g.replay()
+        else:
+            for _ in range(self.num_learning_epochs):
+                for i in range(self.num_mini_batches):
+                    self._gstream.wait_stream(cur)
                     with torch.cuda.stream(self._gstream):
+                        self._ix = views[i]
                         self._zero_grad()
                         self._mb_step()
                     cur.wait_stream(self._gstream)
+            self._ix = self._ix_one
         n = self.num_learning_epochs * self.num_mini_batches
         mean_v, mean_s, lr = (float(x) for x in torch.cat((self._acc / n, self._lr.view(1))).cpu())
         self.learning_rate = lr
