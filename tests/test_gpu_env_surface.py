@@ -226,3 +226,31 @@ def test_train_then_headless_play_resumes_from_checkpoint(tmp_path, monkeypatch)
     c, t = task_registry.get_cfgs("anymal_c_flat")
     c.env.num_envs, c.noise.add_noise, c.domain_rand.randomize_friction, c.domain_rand.push_robots = 4096, True, True, True
     t.runner.resume = False
+
+
+def test_resume_continues_training_on_the_kernel_update_path(tmp_path):
+    """save -> fresh runner -> load(optimizer too) -> learn: the kernel update (lg_ppo_minibatch + lg_adam_step on the restored
+    torch.optim.Adam state) picks up where the first runner stopped -- same weights and optimiser state as an uninterrupted run."""
+    from legged_games_gym_amd.envs import task_registry
+    from legged_games_gym_amd.utils import get_args
+
+    def make():
+        args = get_args(["--task", "anymal_c_flat", "--num_envs", "256", "--headless", "--sim_device", "cuda:0", "--rl_device", "cuda:0"])
+        env, _ = task_registry.make_env("anymal_c_flat", args)
+        runner, _ = task_registry.make_alg_runner(env, "anymal_c_flat", args, log_root=None)
+        return runner
+    a = make()
+    a.learn(num_learning_iterations=3)
+    ckpt = str(tmp_path / "model_3.pt")
+    a.save(ckpt)
+    b = make()
+    b.load(ckpt)
+    assert a.alg._mlp is not None, "the flat networks must take the learner-kernel path"
+    for pa, pb in zip(a.alg.actor_critic.parameters(), b.alg.actor_critic.parameters()):
+        assert torch.equal(pa, pb)
+    steps = [float(s["step"]) for s in b.alg.optimizer.state.values()]
+    assert steps and all(s == 3 * 20 for s in steps)              # 3 updates x 5 epochs x 4 mini-batches
+    b.learn(num_learning_iterations=3)                            # eager warm-up update, capture, replay on the restored state
+    assert all(float(s["step"]) == 6 * 20 for s in b.alg.optimizer.state.values())
+    assert all(bool(torch.isfinite(p).all()) for p in b.alg.actor_critic.parameters())
+    assert any(not torch.equal(pa, pb) for pa, pb in zip(a.alg.actor_critic.parameters(), b.alg.actor_critic.parameters()))
