@@ -42,3 +42,21 @@ if os.environ.get("TRACE"):
         lib.lg_mlp_trace(buf.data_ptr()); fn(); torch.cuda.synchronize(); lib.lg_mlp_trace(None)
         t = buf.cpu().tolist(); t = [v for v in t if v]
         print(name, "stamps:", len(t), "deltas (s_memtime ticks):", [t[i + 1] - t[i] for i in range(len(t) - 1)], "total", t[-1] - t[0])
+
+# fused mini-batch kernel (forward + PPO loss + backward): timing and phase trace
+from legged_games_gym_amd import capi
+A = 12
+stor = {k: torch.randn(R, d, device="cuda") for k, d in (("actions", A), ("old_mu", A), ("old_lp", 1), ("adv", 1), ("old_v", 1), ("ret", 1))}
+stor["old_sigma"] = torch.full((R, A), 0.8, device="cuda")
+std, d_std, stats = torch.full((A,), 0.8, device="cuda"), torch.zeros(A, device="cuda"), torch.zeros(4, device="cuda")
+b = capi.lg_ppo_batch()
+b.actions, b.old_log_prob, b.old_mu, b.old_sigma = (stor[k].data_ptr() for k in ("actions", "old_lp", "old_mu", "old_sigma"))
+b.advantages, b.old_values, b.returns, b.std = stor["adv"].data_ptr(), stor["old_v"].data_ptr(), stor["ret"].data_ptr(), std.data_ptr()
+b.clip, b.value_coef, b.entropy_coef, b.use_clipped_value, b.d_std, b.stats = 0.2, 1.0, 0.01, 1, d_std.data_ptr(), stats.data_ptr()
+tm = timeit(lambda: tr.ppo_minibatch(rows, b))
+print(f"mb {mb}: lg_ppo_minibatch (forward + loss + backward + reduce) {tm:.1f} us ({3 * flops_fwd / tm / 1e6:.1f} TFLOP/s)")
+if os.environ.get("TRACE"):
+    buf = torch.zeros(64, dtype=torch.int64, device="cuda")
+    tr.lib.lg_mlp_trace(buf.data_ptr()); tr.ppo_minibatch(rows, b); torch.cuda.synchronize(); tr.lib.lg_mlp_trace(None)
+    t = [v for v in buf.cpu().tolist() if v]
+    print("ppo_minibatch stamps:", len(t), "deltas:", [t[i + 1] - t[i] for i in range(len(t) - 1)], "total", t[-1] - t[0])
