@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LG_ABI_VERSION        18
+#define LG_ABI_VERSION        19
 
 #define LG_MAX_LIMBS          4
 #define LG_MAX_CHAIN          6
@@ -289,6 +289,9 @@ typedef struct lg_rollout_step {
     float   *storage_time_outs;       /* [N] 0/1, may be NULL */
     float   *cur_return, *cur_length; /* [N] running episode return / length, may both be NULL */
     float   *sums;                    /* [3] += {return, length, 1} of every episode that ended this step */
+    const float *std;                 /* [num_actions] policy std, may be NULL; with it the kernel also stores ...           */
+    float   *storage_sigma;           /* ... [N, num_actions] the broadcast std and                                          */
+    float   *storage_log_prob;        /* ... [N] log N(action; mean, std) summed over actions (rsl_rl PPO.act, [EXTERNAL])   */
     int32_t  num_envs, num_obs, num_actions;
 } lg_rollout_step;
 /* Store the transition and update the episode statistics in one launch.  Asynchronous, capturable. */

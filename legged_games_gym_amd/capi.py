@@ -16,7 +16,7 @@ from typing import Dict, Optional
 
 import numpy as np
 
-LG_ABI_VERSION = 18
+LG_ABI_VERSION = 19
 LG_ADAM_SCRATCH_FLOATS = 2050
 LG_MAX_LIMBS, LG_MAX_CHAIN, LG_MAX_DOF = 4, 6, 12
 LG_MAX_LIMB_POINTS, LG_MAX_BASE_POINTS, LG_MAX_BODIES = 8, 4, 20
@@ -192,7 +192,7 @@ class lg_rollout_step(C.Structure):
     """include/legged_hip.h: lg_rollout_step."""
     _fields_ = [(n, C.c_void_p) for n in ("obs", "actions", "mean", "rewards", "dones", "time_outs", "storage_obs", "storage_actions",
                                           "storage_mu", "storage_rewards", "storage_dones", "storage_time_outs", "cur_return", "cur_length",
-                                          "sums")] + [("num_envs", i32), ("num_obs", i32), ("num_actions", i32)]
+                                          "sums", "std", "storage_sigma", "storage_log_prob")] + [("num_envs", i32), ("num_obs", i32), ("num_actions", i32)]
 
 
 class lg_adam_tensor(C.Structure):

@@ -1597,7 +1597,8 @@ int lg_rollout_record(const lg_rollout_step *s, void *stream) {
     if ((s->cur_return != nullptr) != (s->cur_length != nullptr) || (s->cur_return && !s->sums)) return fail(-1, "incomplete episode statistics");
     lg::RecordArgs a{s->obs, s->actions, s->mean, s->rewards, s->dones, s->time_outs, s->storage_obs, s->storage_actions, s->storage_mu,
                      s->storage_rewards, s->storage_dones, s->storage_time_outs, s->cur_return, s->cur_length, s->sums,
-                     s->num_envs, s->num_obs, s->num_actions};
+                     s->std, s->storage_sigma, s->storage_log_prob, s->num_envs, s->num_obs, s->num_actions};
+    if (s->std && (!s->storage_sigma || !s->storage_log_prob)) return fail(-1, "std given without storage_sigma / storage_log_prob");
     const int64_t n = (int64_t)s->num_envs * s->num_obs;
     hipLaunchKernelGGL(lg::k_rollout_record, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());

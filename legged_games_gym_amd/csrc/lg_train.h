@@ -614,6 +614,7 @@ struct RecordArgs {
     const float *obs, *actions, *mean, *rewards; const uint8_t *dones, *time_outs;           // this step: [N, .] / [N]
     float *st_obs, *st_actions, *st_mu, *st_rewards; uint8_t *st_dones; float *st_time_outs;  // storage slices of step t
     float *cur_rew, *cur_len, *sums;                                                         // running episode return / length [N]; {sum_rew, sum_len, count}
+    const float *std; float *st_sigma, *st_log_prob;                                         // optional: policy std [A] -> sigma[t] [N, A], log pi(a) [N]
     int32_t num_envs, num_obs, num_actions;
 };
 __global__ void __launch_bounds__(256) k_rollout_record(const RecordArgs A) {
@@ -626,6 +627,16 @@ __global__ void __launch_bounds__(256) k_rollout_record(const RecordArgs A) {
         A.st_actions[j] = A.actions[j]; A.st_mu[j] = A.mean[j];
     }
     if (k != 0) return;
+    if (A.std) {                                       // Normal(mean, std).log_prob(action).sum(-1) and the broadcast std, as PPO.act stores them
+        float lp = 0.0f;
+        for (int a = 0; a < A.num_actions; a++) {
+            const size_t j = (size_t)env * A.num_actions + a;
+            const float sg = A.std[a], z = (A.actions[j] - A.mean[j]) / sg;
+            lp += -0.5f * z * z - __logf(sg) - 0.918938533f;
+            A.st_sigma[j] = sg;
+        }
+        A.st_log_prob[env] = lp;
+    }
     const float r = A.rewards[env];
     const uint8_t d = A.dones[env];
     A.st_rewards[env] = r; A.st_dones[env] = d;

@@ -19,8 +19,9 @@ def _linears(seq: nn.Sequential) -> List[nn.Linear]:
 class MlpTrainer:
     """Forward / backward of up to two ``nn.Sequential`` MLPs (actor, critic) over a mini-batch of storage rows."""
 
-    def __init__(self, nets: Sequence[nn.Sequential], inputs: Sequence[torch.Tensor], mb: int):
+    def __init__(self, nets: Sequence[nn.Sequential], inputs: Sequence[torch.Tensor], mb: int, forward_only: bool = False):
         self.lib = capi.load_library()
+        self.forward_only = forward_only           # no .grad tensors, no workspace (rollout-time users, under inference_mode)
         self.nets = list(nets)
         self.inputs = list(inputs)                 # flattened [R, in] row sources (rollout storage views)
         self.mb = int(mb)
@@ -31,10 +32,10 @@ class MlpTrainer:
             return
         dev = self.inputs[0].device
         self.outputs = [torch.empty(self.mb, l[-1].out_features, device=dev) for l in self.layers]
-        self.grad_outputs = [torch.zeros_like(o) for o in self.outputs]
+        self.grad_outputs = [] if forward_only else [torch.zeros_like(o) for o in self.outputs]
         self.desc = (capi.lg_mlp_net * len(self.nets))()
         self.refresh()
-        need = self.lib.lg_mlp_workspace_bytes(self.desc, len(self.nets))
+        need = 0 if forward_only else self.lib.lg_mlp_workspace_bytes(self.desc, len(self.nets))
         self.workspace = torch.empty(need // 4, device=dev)
         probe = self.lib.lg_mlp_forward(self.desc, len(self.nets), None, self.mb, torch.cuda.current_stream(dev).cuda_stream)
         self.supported = probe == 0                # -4: this MLP shape is not built
@@ -45,12 +46,16 @@ class MlpTrainer:
             d = self.desc[n]
             assert x.is_contiguous() and x.dtype == torch.float32
             for i, m in enumerate(layers):
+                d.weights[i], d.biases[i] = m.weight.data_ptr(), m.bias.data_ptr()
+                if self.forward_only:
+                    continue
                 for prm in (m.weight, m.bias):
                     if prm.grad is None:
                         prm.grad = torch.zeros_like(prm)
-                d.weights[i], d.biases[i] = m.weight.data_ptr(), m.bias.data_ptr()
                 d.grad_weights[i], d.grad_biases[i] = m.weight.grad.data_ptr(), m.bias.grad.data_ptr()
-            d.input, d.output, d.grad_output = x.data_ptr(), self.outputs[n].data_ptr(), self.grad_outputs[n].data_ptr()
+            d.input, d.output = x.data_ptr(), self.outputs[n].data_ptr()
+            if not self.forward_only:
+                d.grad_output = self.grad_outputs[n].data_ptr()
             dims = [layers[0].in_features] + [m.out_features for m in layers]
             for i, v in enumerate(dims):
                 d.dims[i] = v

@@ -67,6 +67,20 @@ class OnPolicyRunner:
         actions, mean = fused.act_with_mean(obs)
         return actions, mean, env.step(actions)
 
+    def _critic_values(self, st):
+        """critic(obs) for all stored transitions: lg_mlp_forward when the critic has the learner kernels' shape, torch otherwise."""
+        ac = self.alg.actor_critic
+        cobs = (st.privileged_observations if st.privileged_observations is not None else st.observations).flatten(0, 1)
+        tr = getattr(self, "_critic_fwd", None)
+        if tr is None or (tr is not False and (tr.inputs[0].data_ptr() != cobs.data_ptr() or tr.mb != cobs.shape[0])):
+            from .mlp_kernels import MlpTrainer
+            tr = MlpTrainer([ac.critic], [cobs], cobs.shape[0], forward_only=True) if isinstance(ac.critic, torch.nn.Sequential) else False
+            self._critic_fwd = tr
+        if tr is not False and tr.supported:
+            tr.refresh()                              # parameter addresses (stable; the values follow the optimiser)
+            return tr.forward(None)[0]
+        return ac.evaluate(cobs)
+
     def _rollout_steps_fused(self, stats):
         env, alg, fused = self.env, self.alg, self._fused
         st, T = alg.storage, self.num_steps_per_env
@@ -76,6 +90,8 @@ class OnPolicyRunner:
         step.num_envs, step.num_obs, step.num_actions = env.num_envs, st.observations.shape[-1], st.actions.shape[-1]
         step.cur_return, step.cur_length, step.sums = p(stats["cur_rew"]), p(stats["cur_len"]), p(stats["_sums"])
         stream = torch.cuda.current_stream(self.device).cuda_stream
+        ac = alg.actor_critic
+        step.std = p(ac.std)                          # log-prob and sigma of the transition are stored by the same launch
         for t in range(T):
             prev_obs = obs
             actions, mean, (obs, _, rewards, dones, infos) = self._fused_env_step(obs)
@@ -85,16 +101,13 @@ class OnPolicyRunner:
             step.time_outs = p(touts) if touts is not None else None
             step.storage_obs, step.storage_actions, step.storage_mu = p(st.observations[t]), p(st.actions[t]), p(st.mu[t])
             step.storage_rewards, step.storage_dones, step.storage_time_outs = p(st.rewards[t]), p(st.dones[t]), p(self._time_outs[t])
+            step.storage_sigma, step.storage_log_prob = p(st.sigma[t]), p(st.actions_log_prob[t])
             assert dones.element_size() == 1 and (touts is None or touts.element_size() == 1) and rewards.is_contiguous()   # bool / uint8 flags
             rc = lib.lg_rollout_record(step, stream)
             if rc != 0:
                 raise RuntimeError(f"lg_rollout_record failed ({rc}): {lib.lg_last_error().decode()}")
         st.step = T
-        ac = alg.actor_critic
-        st.values.copy_(ac.evaluate(st.observations.flatten(0, 1)).view(T, -1, 1))            # critic once on all transitions
-        st.sigma.copy_(ac.std.detach().expand_as(st.sigma))
-        lp = torch.distributions.Normal(st.mu, st.sigma, validate_args=False).log_prob(st.actions).sum(dim=-1, keepdim=True)
-        st.actions_log_prob.copy_(lp)
+        st.values.copy_(self._critic_values(st).view(T, -1, 1))                                # critic once on all transitions
         st.rewards.add_(alg.gamma * st.values * self._time_outs)                               # bootstrap on time-outs (PPO.process_env_step)
         return obs, obs
 

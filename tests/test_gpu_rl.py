@@ -205,6 +205,9 @@ def test_rollout_record_kernel_matches_the_torch_bookkeeping():
     step = capi.lg_rollout_step()
     step.num_envs, step.num_obs, step.num_actions = N, O, A
     step.cur_return, step.cur_length, step.sums = cur_rew.data_ptr(), cur_len.data_ptr(), sums.data_ptr()
+    std = 0.5 + torch.rand(A, device="cuda", generator=g)
+    st["sig"], st["lp"] = torch.zeros(T, N, A, device="cuda"), torch.zeros(T, N, 1, device="cuda")
+    step.std = std.data_ptr()
     keep = []
     for t in range(T):
         obs, act, mu, rew = r(N, O), r(N, A), r(N, A), r(N)
@@ -214,6 +217,7 @@ def test_rollout_record_kernel_matches_the_torch_bookkeeping():
         step.obs, step.actions, step.mean, step.rewards, step.dones, step.time_outs = (x.data_ptr() for x in (obs, act, mu, rew, done, tout))
         step.storage_obs, step.storage_actions, step.storage_mu = st["obs"][t].data_ptr(), st["act"][t].data_ptr(), st["mu"][t].data_ptr()
         step.storage_rewards, step.storage_dones, step.storage_time_outs = st["rew"][t].data_ptr(), st["done"][t].data_ptr(), st["tout"][t].data_ptr()
+        step.storage_sigma, step.storage_log_prob = st["sig"][t].data_ptr(), st["lp"][t].data_ptr()
         assert lib.lg_rollout_record(step, torch.cuda.current_stream().cuda_stream) == 0, lib.lg_last_error()
         d = done.float()
         ref["cur_rew"] += rew; ref["cur_len"] += 1.0
@@ -222,6 +226,8 @@ def test_rollout_record_kernel_matches_the_torch_bookkeeping():
     for t, (obs, act, mu, rew, done, tout) in enumerate(keep):
         assert torch.equal(st["obs"][t], obs) and torch.equal(st["act"][t], act) and torch.equal(st["mu"][t], mu)
         assert torch.equal(st["rew"][t, :, 0], rew) and torch.equal(st["done"][t, :, 0], done) and torch.equal(st["tout"][t, :, 0], tout.float())
+        want_lp = torch.distributions.Normal(mu, std.expand_as(mu)).log_prob(act).sum(-1)
+        assert torch.equal(st["sig"][t], std.expand(N, A)) and float((st["lp"][t, :, 0] - want_lp).abs().max()) < 2e-5
     assert torch.equal(cur_len, ref["cur_len"]) and float((cur_rew - ref["cur_rew"]).abs().max()) < 1e-6
     assert float(sums[2]) == float(ref["sums"][2]) and float(sums[1]) == float(ref["sums"][1])
     assert abs(float(sums[0]) - float(ref["sums"][0])) < 1e-3          # atomic accumulation order
