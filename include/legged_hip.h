@@ -333,7 +333,8 @@ int  lg_ppo_loss(const float *mu, const float *std, const float *value, const in
 
 const char *lg_last_error(void);
 int  lg_abi_version(void);
-/* sizeof of the ABI structs (0 params, 1 robot_model, 2 buffers, 3 point) so a binding can verify its layout. */
+/* sizeof of the ABI structs (0 params, 1 robot_model, 2 buffers, 3 point, 4 mlp_net, 5 adam_tensor, 6 rollout_step, 7 ppo_batch;
+ * the CPU oracle knows 0-3) so a binding can verify its layout. */
 int  lg_sizeof(int which);
 
 #ifdef __cplusplus

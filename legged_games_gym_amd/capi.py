@@ -268,7 +268,8 @@ def bind_prototypes(lib, prefix: str):
         fn = getattr(lib, prefix + name)
         fn.argtypes, fn.restype = args, res
     sizeof = getattr(lib, prefix + "sizeof")
-    for which, st in enumerate((lg_params, lg_robot_model, lg_buffers, lg_point)):
+    structs = (lg_params, lg_robot_model, lg_buffers, lg_point) + ((lg_mlp_net, lg_adam_tensor, lg_rollout_step, lg_ppo_batch) if prefix == "lg_" else ())
+    for which, st in enumerate(structs):
         if sizeof(which) != C.sizeof(st):
             raise RuntimeError(f"struct layout mismatch for {st.__name__}: C {sizeof(which)} vs ctypes {C.sizeof(st)}")
     return lib

@@ -1848,7 +1848,9 @@ int lg_debug_profile(lg_sim *s, unsigned long long *out16 /* [LG_NPROF] */, int 
 #endif
 int lg_sizeof(int which) {
     switch (which) { case 0: return (int)sizeof(lg_params); case 1: return (int)sizeof(lg_robot_model);
-                     case 2: return (int)sizeof(lg_buffers); case 3: return (int)sizeof(lg_point); default: return -1; }
+                     case 2: return (int)sizeof(lg_buffers); case 3: return (int)sizeof(lg_point);
+                     case 4: return (int)sizeof(lg_mlp_net); case 5: return (int)sizeof(lg_adam_tensor);
+                     case 6: return (int)sizeof(lg_rollout_step); case 7: return (int)sizeof(lg_ppo_batch); default: return -1; }
 }
 
 int lg_create(const lg_params *params, const lg_robot_model *model, const float *actuator_weights, int device_id, lg_sim **out) {
