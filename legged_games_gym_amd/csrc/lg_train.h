@@ -1,4 +1,5 @@
-// lg_train.h -- PPO mini-batch MLP forward / backward on the matrix cores (the learner half of the rollout+update loop).
+// lg_train.h -- the learner half of the rollout+update loop: PPO mini-batch MLP forward / loss / backward on the matrix cores
+// (k_mlp_train, k_mlp_reduce), gradient clip + Adam (k_adam_*), rollout bookkeeping (k_rollout_record).
 //
 // Stands in for the autograd pass over rsl_rl's ActorCritic MLPs ([EXTERNAL]; Linear/ELU x3 + Linear, dims from reference
 // legged_robot_config.py:204-209) inside PPO.update(): y = net(x[rows]) and, given dL/dy, the gradients of all weights
@@ -7,7 +8,8 @@
 // and then walks its row tiles with every operand coming from LDS -- a wave per SIMD cannot hide L2 latency eight times
 // per row tile.  Activations never leave LDS, and the weight gradients are accumulated in MFMA accumulators across all
 // the row tiles a workgroup walks, then written once as a per-workgroup partial that k_mlp_reduce sums in a fixed order
-// (deterministic, no atomics).
+// (deterministic, no atomics).  Builds of the one kernel template: forward only (lg_mlp_forward), backward from a given dL/dy
+// (lg_mlp_backward), and forward + PPO loss + backward in one pass (lg_ppo_minibatch, the one PPO.update uses).
 //
 // Tile algebra (v_mfma_f32_16x16x4_f32, D[i][j] += A[i][k] B[k][j]; A: lane l holds A[l&15][l>>4], B: lane l holds
 // B[l>>4][l&15], D: lane l holds D[4(l>>4)+c][l&15]):
@@ -273,8 +275,8 @@ __global__ void __launch_bounds__(64 * LG_TRAIN_WAVES * SLOTS) k_mlp_train(const
 #pragma unroll
         for (int i = 0; i < P3::per_wave; i++) a3[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    // The inputs of row tile rt + gridDim.x are requested while tile rt is computed: a lone wave per SIMD has nothing else
-    // to hide the gather's two dependent global loads (row index, then the row) behind.
+    // The inputs of the group's next row tile are requested while the current one is computed, and the row indices one tile
+    // further ahead: nothing else hides the gather's two dependent global loads (row index, then the row).
     static_assert(D0T <= LG_TRAIN_WAVES, "one input tile per wave");
     float4 xv_next = make_float4(0.f, 0.f, 0.f, 0.f), dy_next = make_float4(0.f, 0.f, 0.f, 0.f);
     int64_t src_next = 0;                                          // storage row of this lane in the tile requested NEXT
