@@ -26,8 +26,10 @@ class MlpTrainer:
         self.inputs = list(inputs)                 # flattened [R, in] row sources (rollout storage views)
         self.mb = int(mb)
         self.layers = [_linears(n) for n in self.nets]
+        # exactly Linear-ELU-Linear-ELU-Linear-ELU-Linear with the default ELU (alpha = 1): what the kernels compute
         self.supported = all(len(l) == 4 for l in self.layers) and all(
-            all(isinstance(m, (nn.Linear, nn.ELU)) for m in n) for n in self.nets)
+            len(n) == 7 and all(isinstance(m, nn.Linear if i % 2 == 0 else nn.ELU) and (i % 2 == 0 or m.alpha == 1.0) for i, m in enumerate(n))
+            for n in self.nets)
         if not self.supported:
             return
         dev = self.inputs[0].device
