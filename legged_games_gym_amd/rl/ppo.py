@@ -62,13 +62,8 @@ class RolloutStorage:
         if not self.values.is_cuda:
             return False
         if getattr(self, "_lib", None) is None:
-            try:
-                from .. import capi
-                self._lib = capi.load_library()
-            except Exception:                      # rl/ stays usable without the extension (plain rsl_rl semantics)
-                self._lib = False
-        if not self._lib:
-            return False
+            from .. import capi
+            self._lib = capi.load_library()        # on a GPU the extension is the product path: a missing build fails loudly here
         T, N = self.num_transitions_per_env, self.num_envs
         lv = last_values.reshape(-1).contiguous().float()
         rc = self._lib.lg_gae_returns(self.rewards.data_ptr(), self.values.data_ptr(), self.dones.data_ptr(), lv.data_ptr(), float(gamma), float(lam),
@@ -263,11 +258,8 @@ class PPO:
         if not self._fused_loss:
             return False
         if self._lib is None:
-            try:
-                from .. import capi
-                self._lib = capi.load_library()
-            except Exception:
-                self._lib = False
+            from .. import capi
+            self._lib = capi.load_library()        # cuda device: no silent torch substitute for a missing extension
         ac = self.actor_critic
         return bool(self._lib) and hasattr(ac, "actor") and hasattr(ac, "critic") and hasattr(ac, "std") and ac.std.numel() <= 16
 
