@@ -1481,7 +1481,7 @@ static int mlp_fill(const lg_mlp_net *nets, int32_t n_nets, const int64_t *rows,
             num_cus = 256;
     }
     wgs = num_cus / n_nets;
-    if (partials && wgs * slots > LG_TRAIN_WGS) wgs = LG_TRAIN_WGS / slots;       // backward: one partial-sum slice per group
+    if (partials && wgs > LG_TRAIN_WGS) wgs = LG_TRAIN_WGS;                       // backward: one partial-sum slice per workgroup
     if (wgs * slots > a.n_tiles) wgs = (a.n_tiles + slots - 1) / slots;
     if (wgs < 1) wgs = 1;
     for (int n = 0; n < n_nets; n++) {
@@ -1554,7 +1554,7 @@ static int mlp_backward_launch(const lg_mlp_net *nets, int32_t n_nets, const int
             r.gw[n][l] = nets[n].grad_weights[l]; r.gb[n][l] = nets[n].grad_biases[l];
         }
     }
-    r.n_partials = wgs * LG_BWD_SLOTS;
+    r.n_partials = wgs;                        // the groups of a workgroup fold their sums before writing
     if (batch) {
         if (n_nets != 2 || nets[1].dims[4] != 1) return fail(-1, "lg_ppo_minibatch needs nets = {actor, critic (one output)}");
         if (!rows || !batch->actions || !batch->old_log_prob || !batch->old_mu || !batch->old_sigma || !batch->advantages || !batch->old_values ||

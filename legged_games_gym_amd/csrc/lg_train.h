@@ -465,22 +465,63 @@ __global__ void __launch_bounds__(64 * LG_TRAIN_WAVES * SLOTS) k_mlp_train(const
         __syncthreads();
         LG_TR();
     }
-    if (LOSS && wave == LG_TRAIN_WAVES - 1) {                      // per-group loss partials: d_std[16] | surrogate, value loss, KL sums
-        float *ex = N.partial + (size_t)(blockIdx.x * SLOTS + slot) * N.part_stride + N.grad_floats;
+    // The groups of a workgroup fold their accumulators through LDS (the activation areas are free now) in group order, so each
+    // workgroup writes ONE partial: half the workspace traffic and half the work of k_mlp_reduce with 2 groups.
+    if (BWD) {
+        constexpr int NACC = P0::per_wave + P1::per_wave + P2::per_wave + P3::per_wave + 2;       // + loss terms (2 quads)
+        static_assert(SLOTS == 1 || NACC * 64 * LG_TRAIN_WAVES * 4 <= S::floats, "accumulator exchange must fit the LDS");
+        float4 *xch = reinterpret_cast<float4 *>(lds) + (size_t)(wave * 64 + lane) * NACC;       // indexed by ROLE: same pairs in every group
+        if (LOSS && wave == LG_TRAIN_WAVES - 1) {
 #pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
+            for (int o = 1; o < 16; o <<= 1) {
 #pragma unroll
-            for (int c = 0; c < 4; c++) gstd[c] += __shfl_xor(gstd[c], o);
-            sum_sur += __shfl_xor(sum_sur, o); sum_kl += __shfl_xor(sum_kl, o); sum_val += __shfl_xor(sum_val, o);
+                for (int c = 0; c < 4; c++) gstd[c] += __shfl_xor(gstd[c], o);
+                sum_sur += __shfl_xor(sum_sur, o); sum_kl += __shfl_xor(sum_kl, o); sum_val += __shfl_xor(sum_val, o);
+            }
         }
+        for (int s_ = SLOTS - 1; s_ >= 1; s_--) {                  // group s_ hands its sums to group s_ - 1
+            __syncthreads();
+            if (slot == s_) {
+                int n = 0;
+#pragma unroll
+                for (int i = 0; i < P0::per_wave; i++) xch[n++] = make_float4(a0[i][0], a0[i][1], a0[i][2], a0[i][3]);
+#pragma unroll
+                for (int i = 0; i < P1::per_wave; i++) xch[n++] = make_float4(a1[i][0], a1[i][1], a1[i][2], a1[i][3]);
+#pragma unroll
+                for (int i = 0; i < P2::per_wave; i++) xch[n++] = make_float4(a2[i][0], a2[i][1], a2[i][2], a2[i][3]);
+#pragma unroll
+                for (int i = 0; i < P3::per_wave; i++) xch[n++] = make_float4(a3[i][0], a3[i][1], a3[i][2], a3[i][3]);
+                xch[n++] = make_float4(gstd[0], gstd[1], gstd[2], gstd[3]);
+                xch[n++] = make_float4(sum_sur, sum_val, sum_kl, 0.0f);
+            }
+            __syncthreads();
+            if (slot == s_ - 1) {
+                int n = 0;
+                auto add = [&](f32x4 &a) { const float4 v = xch[n++]; a[0] += v.x; a[1] += v.y; a[2] += v.z; a[3] += v.w; };
+#pragma unroll
+                for (int i = 0; i < P0::per_wave; i++) add(a0[i]);
+#pragma unroll
+                for (int i = 0; i < P1::per_wave; i++) add(a1[i]);
+#pragma unroll
+                for (int i = 0; i < P2::per_wave; i++) add(a2[i]);
+#pragma unroll
+                for (int i = 0; i < P3::per_wave; i++) add(a3[i]);
+                const float4 gs = xch[n++], sm = xch[n++];
+                gstd[0] += gs.x; gstd[1] += gs.y; gstd[2] += gs.z; gstd[3] += gs.w;
+                sum_sur += sm.x; sum_val += sm.y; sum_kl += sm.z;
+            }
+        }
+    }
+    if (LOSS && slot == 0 && wave == LG_TRAIN_WAVES - 1) {         // loss partials: d_std[16] | surrogate, value loss, KL sums
+        float *ex = N.partial + (size_t)blockIdx.x * N.part_stride + N.grad_floats;
         if ((lane & 15) == 0) {
 #pragma unroll
             for (int c = 0; c < 4; c++) ex[4 * g + c] = gstd[c];
             if (g == 0) { ex[16] = sum_sur * A.ppo.inv_n; ex[17] = sum_val * A.ppo.inv_n; ex[18] = sum_kl * A.ppo.inv_n; ex[19] = 0.0f; }
         }
     }
-    if (BWD) {
-        float *part = N.partial + (size_t)(blockIdx.x * SLOTS + slot) * N.part_stride;
+    if (BWD && slot == 0) {
+        float *part = N.partial + (size_t)blockIdx.x * N.part_stride;
         train_flush<D0T, D1T>(a0, part, d0, d1, wave, lane); part += (size_t)d1 * d0 + d1;
         train_flush<D1T, D2T>(a1, part, d1, d2, wave, lane); part += (size_t)d2 * d1 + d2;
         train_flush<D2T, D3T>(a2, part, d2, d3, wave, lane); part += (size_t)d3 * d2 + d3;
