@@ -19,6 +19,7 @@
 //   biases    db[f]           = g_{l+1}[f][row] * 1           same as dW with an all-ones B operand (an extra "input tile")
 // where g is the gradient w.r.t. the pre-activation (ELU' folded in from the stored post-activation: x > 0 ? 1 : x + 1).
 #pragma once
+#include <type_traits>
 #include "lg_policy.h"
 
 namespace lg {
@@ -112,7 +113,7 @@ template <int IN_T, int OUT_T>
 LG_DEV void train_forward_layer_t(const float *wl, const float (*xinT)[16][LG_TT], float (*xoutT)[16][LG_TT], int wave, int lane) {
     using L = LdsLayer<IN_T, OUT_T>;
     const int g = lane >> 4;
-#pragma unroll 1
+#pragma unroll
     for (int o = wave; o < OUT_T; o += LG_TRAIN_WAVES) {
         const float *wr = wl + (16 * o + (lane & 15)) * L::stride + 4 * g;
         const float4 bv = *reinterpret_cast<const float4 *>(wl + L::w_floats + 16 * o + 4 * g);
@@ -135,7 +136,7 @@ template <int IN_T, int OUT_T, bool ACT>
 LG_DEV void train_forward_layer(const float *wl, const float4 (*xin)[64], float4 (*xout)[64], int wave, int lane) {
     using L = LdsLayer<IN_T, OUT_T>;
     const int g = lane >> 4;
-#pragma unroll 1
+#pragma unroll
     for (int o = wave; o < OUT_T; o += LG_TRAIN_WAVES) {
         const float *wr = wl + (16 * o + (lane & 15)) * L::stride + 4 * g;
         const float4 bv = *reinterpret_cast<const float4 *>(wl + L::w_floats + 16 * o + 4 * g);
@@ -161,7 +162,7 @@ LG_DEV void train_backward_layer(const float *wl, const float (*goutT)[16][LG_TT
                                  float (*ginT)[16][LG_TT], int wave, int lane) {
     using L = LdsLayer<IN_T, OUT_T>;
     const int g = lane >> 4;
-#pragma unroll 1
+#pragma unroll
     for (int ti = wave; ti < IN_T; ti += LG_TRAIN_WAVES) {
         const float *wc = wl + 4 * g * L::stride + 16 * ti + (lane & 15);      // column of W = row of W^T
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -337,133 +338,145 @@ __global__ void __launch_bounds__(64 * LG_TRAIN_WAVES * SLOTS) k_mlp_train(const
         f0.store(wl0, threadIdx.x); f1.store(wl1, threadIdx.x); f2.store(wl2, threadIdx.x); f3.store(wl3, threadIdx.x);
     }
     LG_TR();
-#pragma unroll 1
-    for (int it = 0; it < n_iter; it++, rt += stride) {
-        const bool active = rt < A.n_tiles;
-        const int r = rt * 16 + (lane & 15);
-        const bool live = active && r < A.mb;
-        const float4 dyv = active ? dy_next : make_float4(0.f, 0.f, 0.f, 0.f);   // an idle group still runs the barriers; it adds zeros
-        const float4 actv = act_next, omuv = omu_next, osgv = osg_next;
-        const float s0v = s0_next, s1v = s1_next;
-        if (wave < D0T) {
-            if (BWD) tile_store_t(xT + X0, wave, lane, xv_next); else x[X0 + wave][lane] = xv_next;
-        }
-        LG_TR();
-        if (rt + stride < A.n_tiles) request(rt + stride, src_next);           // its index was loaded an iteration ago
-        if (rt + 2 * stride < A.n_tiles) src_next = row_index(rt + 2 * stride);
-        LG_TR();
-        __syncthreads();                                           // (first pass: also the weights are in LDS)
-        LG_TR();
-        if (BWD) train_forward_layer_t<D0T, D1T>(wl0, xT + X0, xT + X1, wave, lane);
-        else train_forward_layer<D0T, D1T, true>(wl0, x + X0, x + X1, wave, lane);
-        LG_TR();
-        __syncthreads();
-        LG_TR();
-        if (BWD) train_forward_layer_t<D1T, D2T>(wl1, xT + X1, xT + X2, wave, lane);
-        else train_forward_layer<D1T, D2T, true>(wl1, x + X1, x + X2, wave, lane);
-        LG_TR();
-        __syncthreads();
-        LG_TR();
-        if (BWD) train_forward_layer_t<D2T, D3T>(wl2, xT + X2, xT + X3, wave, lane);
-        else train_forward_layer<D2T, D3T, true>(wl2, x + X2, x + X3, wave, lane);
-        if (BWD && !LOSS && wave == LG_TRAIN_WAVES - 1) tile_store_t(gT + G4, 0, lane, dyv);
-        LG_TR();
-        __syncthreads();
-        LG_TR();
-        if (LOSS) {
-            if (wave == LG_TRAIN_WAVES - 1) {
-                // output layer in registers: lane (row l&15, group g) holds y[4g + c]
-                using L3 = LdsLayer<D3T, 1>;
-                const float4 bv = *reinterpret_cast<const float4 *>(wl3 + L3::w_floats + 4 * g);
-                f32x4 y = {bv.x, bv.y, bv.z, bv.w};
-#pragma unroll
-                for (int t = 0; t < D3T; t++) {
-                    const float4 wv = *reinterpret_cast<const float4 *>(wl3 + (lane & 15) * L3::stride + 16 * t + 4 * g);
-                    const float4 xv = tile_load_b(xT + X3, t, lane);
-                    y = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.x, xv.x, y, 0, 0, 0);
-                    y = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.y, xv.y, y, 0, 0, 0);
-                    y = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.z, xv.z, y, 0, 0, 0);
-                    y = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.w, xv.w, y, 0, 0, 0);
-                }
-                const PpoArgs &P = A.ppo;
-                float d[4] = {0.f, 0.f, 0.f, 0.f};
-                if (actor) {
-                    const float av[4] = {actv.x, actv.y, actv.z, actv.w}, om[4] = {omuv.x, omuv.y, omuv.z, omuv.w}, os[4] = {osgv.x, osgv.y, osgv.z, osgv.w};
-                    float z[4], lp = 0.0f, kl = 0.0f;
-#pragma unroll
-                    for (int c = 0; c < 4; c++) {
-                        z[c] = 0.0f;
-                        if (4 * g + c < d4) {
-                            z[c] = (av[c] - y[c]) * isg[c];
-                            lp += -0.5f * z[c] * z[c] - lsg[c] - 0.918938533f;                     // log N(a; mu, sigma)
-                            kl += __logf(sg[c] / os[c] + 1.0e-5f) + (os[c] * os[c] + (om[c] - y[c]) * (om[c] - y[c])) * (0.5f * isg[c] * isg[c]) - 0.5f;
-                        }
-                    }
-                    lp += __shfl_xor(lp, 16); lp += __shfl_xor(lp, 32);                            // the row's actions live in 4 lanes
-                    kl += __shfl_xor(kl, 16); kl += __shfl_xor(kl, 32);
-                    const float ad = s1v, ratio = __expf(lp - s0v);
-                    const float t1 = -ad * ratio, t2 = -ad * fminf(fmaxf(ratio, 1.0f - P.clip), 1.0f + P.clip);
-                    const bool inside = ratio >= 1.0f - P.clip && ratio <= 1.0f + P.clip;
-                    const float dlp = (t1 > t2 || inside) ? -ad * ratio : (t1 == t2 ? -0.5f * ad * ratio : 0.0f);
-                    if (live) {
-#pragma unroll
-                        for (int c = 0; c < 4; c++) if (4 * g + c < d4) {
-                            d[c] = P.inv_n * dlp * z[c] * isg[c];                                  // d lp / d mu = (a - mu) / sigma^2
-                            gstd[c] += P.inv_n * dlp * (z[c] * z[c] - 1.0f) * isg[c];              // d lp / d sigma
-                        }
-                        if (g == 0) { sum_sur += fmaxf(t1, t2); sum_kl += kl; }
-                    }
-                } else if (g == 0) {
-                    const float v = y[0], tv = s0v, R = s1v;
-                    float dv, vl;
-                    if (P.clipped_value) {
-                        const float dvt = v - tv, vc = tv + fminf(fmaxf(dvt, -P.clip), P.clip);
-                        const float v1 = (v - R) * (v - R), v2 = (vc - R) * (vc - R);
-                        const bool in_v = dvt >= -P.clip && dvt <= P.clip;
-                        vl = fmaxf(v1, v2);
-                        dv = (v1 > v2 || in_v) ? 2.0f * (v - R) : (v1 == v2 ? (v - R) : 0.0f);
-                    } else {
-                        vl = (R - v) * (R - v);
-                        dv = 2.0f * (v - R);
-                    }
-                    if (live) { d[0] = P.vcoef * P.inv_n * dv; sum_val += vl; }
-                }
-                tile_store_t(gT + G4, 0, lane, make_float4(d[0], d[1], d[2], d[3]));
+    // The row-tile loop is compiled once per role: with the role a compile-time constant every tile index and LDS tile address
+    // below is an immediate instead of per-access integer arithmetic (the kernel is instruction-issue bound: VALU : MFMA was 3 : 1).
+    // The role branch is wave-uniform and every copy runs the same barrier sequence.
+    auto row_tiles = [&](auto role) {
+        constexpr int wave = decltype(role)::value;                // shadows the runtime role
+    #pragma unroll 1
+        for (int it = 0; it < n_iter; it++, rt += stride) {
+            const bool active = rt < A.n_tiles;
+            const int r = rt * 16 + (lane & 15);
+            const bool live = active && r < A.mb;
+            const float4 dyv = active ? dy_next : make_float4(0.f, 0.f, 0.f, 0.f);   // an idle group still runs the barriers; it adds zeros
+            const float4 actv = act_next, omuv = omu_next, osgv = osg_next;
+            const float s0v = s0_next, s1v = s1_next;
+            if (wave < D0T) {
+                if (BWD) tile_store_t(xT + X0, wave, lane, xv_next); else x[X0 + wave][lane] = xv_next;
             }
             LG_TR();
-            __syncthreads();
-        }
-        if (!BWD) {
-            if (wave == 0) {
-                // the output layer reuses x tile X0 as scratch (its inputs are no longer needed in forward-only mode)
-                train_forward_layer<D3T, 1, false>(wl3, x + X3, x + X0, 0, lane);
-                const float4 yv = x[X0][lane];
-                const float y4[4] = {yv.x, yv.y, yv.z, yv.w};
-#pragma unroll
-                for (int c = 0; c < 4; c++) { const int k = 4 * g + c; if (live && k < d4) N.y[(size_t)r * d4 + k] = y4[c]; }
-            }
+            if (rt + stride < A.n_tiles) request(rt + stride, src_next);           // its index was loaded an iteration ago
+            if (rt + 2 * stride < A.n_tiles) src_next = row_index(rt + 2 * stride);
+            LG_TR();
+            __syncthreads();                                           // (first pass: also the weights are in LDS)
+            LG_TR();
+            if (BWD) train_forward_layer_t<D0T, D1T>(wl0, xT + X0, xT + X1, wave, lane);
+            else train_forward_layer<D0T, D1T, true>(wl0, x + X0, x + X1, wave, lane);
             LG_TR();
             __syncthreads();
             LG_TR();
-            continue;
+            if (BWD) train_forward_layer_t<D1T, D2T>(wl1, xT + X1, xT + X2, wave, lane);
+            else train_forward_layer<D1T, D2T, true>(wl1, x + X1, x + X2, wave, lane);
+            LG_TR();
+            __syncthreads();
+            LG_TR();
+            if (BWD) train_forward_layer_t<D2T, D3T>(wl2, xT + X2, xT + X3, wave, lane);
+            else train_forward_layer<D2T, D3T, true>(wl2, x + X2, x + X3, wave, lane);
+            if (BWD && !LOSS && wave == LG_TRAIN_WAVES - 1) tile_store_t(gT + G4, 0, lane, dyv);
+            LG_TR();
+            __syncthreads();
+            LG_TR();
+            if (LOSS) {
+                if (wave == LG_TRAIN_WAVES - 1) {
+                    // output layer in registers: lane (row l&15, group g) holds y[4g + c]
+                    using L3 = LdsLayer<D3T, 1>;
+                    const float4 bv = *reinterpret_cast<const float4 *>(wl3 + L3::w_floats + 4 * g);
+                    f32x4 y = {bv.x, bv.y, bv.z, bv.w};
+    #pragma unroll
+                    for (int t = 0; t < D3T; t++) {
+                        const float4 wv = *reinterpret_cast<const float4 *>(wl3 + (lane & 15) * L3::stride + 16 * t + 4 * g);
+                        const float4 xv = tile_load_b(xT + X3, t, lane);
+                        y = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.x, xv.x, y, 0, 0, 0);
+                        y = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.y, xv.y, y, 0, 0, 0);
+                        y = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.z, xv.z, y, 0, 0, 0);
+                        y = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.w, xv.w, y, 0, 0, 0);
+                    }
+                    const PpoArgs &P = A.ppo;
+                    float d[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (actor) {
+                        const float av[4] = {actv.x, actv.y, actv.z, actv.w}, om[4] = {omuv.x, omuv.y, omuv.z, omuv.w}, os[4] = {osgv.x, osgv.y, osgv.z, osgv.w};
+                        float z[4], lp = 0.0f, kl = 0.0f;
+    #pragma unroll
+                        for (int c = 0; c < 4; c++) {
+                            z[c] = 0.0f;
+                            if (4 * g + c < d4) {
+                                z[c] = (av[c] - y[c]) * isg[c];
+                                lp += -0.5f * z[c] * z[c] - lsg[c] - 0.918938533f;                     // log N(a; mu, sigma)
+                                kl += __logf(sg[c] / os[c] + 1.0e-5f) + (os[c] * os[c] + (om[c] - y[c]) * (om[c] - y[c])) * (0.5f * isg[c] * isg[c]) - 0.5f;
+                            }
+                        }
+                        lp += __shfl_xor(lp, 16); lp += __shfl_xor(lp, 32);                            // the row's actions live in 4 lanes
+                        kl += __shfl_xor(kl, 16); kl += __shfl_xor(kl, 32);
+                        const float ad = s1v, ratio = __expf(lp - s0v);
+                        const float t1 = -ad * ratio, t2 = -ad * fminf(fmaxf(ratio, 1.0f - P.clip), 1.0f + P.clip);
+                        const bool inside = ratio >= 1.0f - P.clip && ratio <= 1.0f + P.clip;
+                        const float dlp = (t1 > t2 || inside) ? -ad * ratio : (t1 == t2 ? -0.5f * ad * ratio : 0.0f);
+                        if (live) {
+    #pragma unroll
+                            for (int c = 0; c < 4; c++) if (4 * g + c < d4) {
+                                d[c] = P.inv_n * dlp * z[c] * isg[c];                                  // d lp / d mu = (a - mu) / sigma^2
+                                gstd[c] += P.inv_n * dlp * (z[c] * z[c] - 1.0f) * isg[c];              // d lp / d sigma
+                            }
+                            if (g == 0) { sum_sur += fmaxf(t1, t2); sum_kl += kl; }
+                        }
+                    } else if (g == 0) {
+                        const float v = y[0], tv = s0v, R = s1v;
+                        float dv, vl;
+                        if (P.clipped_value) {
+                            const float dvt = v - tv, vc = tv + fminf(fmaxf(dvt, -P.clip), P.clip);
+                            const float v1 = (v - R) * (v - R), v2 = (vc - R) * (vc - R);
+                            const bool in_v = dvt >= -P.clip && dvt <= P.clip;
+                            vl = fmaxf(v1, v2);
+                            dv = (v1 > v2 || in_v) ? 2.0f * (v - R) : (v1 == v2 ? (v - R) : 0.0f);
+                        } else {
+                            vl = (R - v) * (R - v);
+                            dv = 2.0f * (v - R);
+                        }
+                        if (live) { d[0] = P.vcoef * P.inv_n * dv; sum_val += vl; }
+                    }
+                    tile_store_t(gT + G4, 0, lane, make_float4(d[0], d[1], d[2], d[3]));
+                }
+                LG_TR();
+                __syncthreads();
+            }
+            if (!BWD) {
+                if (wave == 0) {
+                    // the output layer reuses x tile X0 as scratch (its inputs are no longer needed in forward-only mode)
+                    train_forward_layer<D3T, 1, false>(wl3, x + X3, x + X0, 0, lane);
+                    const float4 yv = x[X0][lane];
+                    const float y4[4] = {yv.x, yv.y, yv.z, yv.w};
+    #pragma unroll
+                    for (int c = 0; c < 4; c++) { const int k = 4 * g + c; if (live && k < d4) N.y[(size_t)r * d4 + k] = y4[c]; }
+                }
+                LG_TR();
+                __syncthreads();
+                LG_TR();
+                continue;
+            }
+            // output layer: dW3 / db3 and g3 = (W3^T dy) * elu'(x3)
+            train_backward_layer<D3T, 1>(wl3, gT + G4, xT + X3, gT + G3, wave, lane);
+            train_weight_grad<D3T, 1>(gT + G4, xT + X3, a3, wave, lane);
+            LG_TR();
+            __syncthreads();
+            train_backward_layer<D2T, D3T>(wl2, gT + G3, xT + X2, gT + G2, wave, lane);
+            train_weight_grad<D2T, D3T>(gT + G3, xT + X2, a2, wave, lane);
+            LG_TR();
+            __syncthreads();
+            train_backward_layer<D1T, D2T>(wl1, gT + G2, xT + X1, gT + G1, wave, lane);
+            train_weight_grad<D1T, D2T>(gT + G2, xT + X1, a1, wave, lane);
+            LG_TR();
+            __syncthreads();
+            train_weight_grad<D0T, D1T>(gT + G1, xT + X0, a0, wave, lane);
+            LG_TR();
+            __syncthreads();
+            LG_TR();
         }
-        // output layer: dW3 / db3 and g3 = (W3^T dy) * elu'(x3)
-        train_backward_layer<D3T, 1>(wl3, gT + G4, xT + X3, gT + G3, wave, lane);
-        train_weight_grad<D3T, 1>(gT + G4, xT + X3, a3, wave, lane);
-        LG_TR();
-        __syncthreads();
-        train_backward_layer<D2T, D3T>(wl2, gT + G3, xT + X2, gT + G2, wave, lane);
-        train_weight_grad<D2T, D3T>(gT + G3, xT + X2, a2, wave, lane);
-        LG_TR();
-        __syncthreads();
-        train_backward_layer<D1T, D2T>(wl1, gT + G2, xT + X1, gT + G1, wave, lane);
-        train_weight_grad<D1T, D2T>(gT + G2, xT + X1, a1, wave, lane);
-        LG_TR();
-        __syncthreads();
-        train_weight_grad<D0T, D1T>(gT + G1, xT + X0, a0, wave, lane);
-        LG_TR();
-        __syncthreads();
-        LG_TR();
+    };
+    switch (wave) {
+        case 0: row_tiles(std::integral_constant<int, 0>{}); break;
+        case 1: row_tiles(std::integral_constant<int, 1>{}); break;
+        case 2: row_tiles(std::integral_constant<int, 2>{}); break;
+        default: row_tiles(std::integral_constant<int, 3>{}); break;
     }
     // The groups of a workgroup fold their accumulators through LDS (the activation areas are free now) in group order, so each
     // workgroup writes ONE partial: half the workspace traffic and half the work of k_mlp_reduce with 2 groups.
