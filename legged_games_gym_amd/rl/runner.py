@@ -228,14 +228,47 @@ class OnPolicyRunner:
                 fps = int(self.num_steps_per_env * self.env.num_envs / (t2 - t0))
                 mr = statistics.mean(rewbuffer) if len(rewbuffer) else float("nan")
                 ml = statistics.mean(lenbuffer) if len(lenbuffer) else float("nan")
+                row = self._log_scalars(it, fps, t1 - t0, t2 - t1, mean_value_loss, mean_surrogate_loss, mr, ml)
                 print(f"it {it}/{last}  steps/s {fps}  collect {t1 - t0:.3f}s  learn {t2 - t1:.3f}s  value_loss {mean_value_loss:.4f}  "
-                      f"surrogate {mean_surrogate_loss:.4f}  std {self.alg.actor_critic.std.mean().item():.3f}  "
+                      f"surrogate {mean_surrogate_loss:.4f}  std {row['Policy/mean_noise_std']:.3f}  "
                       f"mean_reward {mr:.3f}  mean_ep_len {ml:.1f}")
                 if it % self.save_interval == 0:
                     self.save(os.path.join(self.log_dir, f"model_{it}.pt"))
         self.current_learning_iteration += num_learning_iterations
         if self.log_dir is not None:
             self.save(os.path.join(self.log_dir, f"model_{self.current_learning_iteration}.pt"))
+
+    def _log_scalars(self, it, fps, t_collect, t_learn, value_loss, surrogate, mean_reward, mean_len):
+        """Per-iteration scalars under rsl_rl's TensorBoard tag names ([EXTERNAL] OnPolicyRunner.log): always to
+        ``<log_dir>/progress.csv`` (no dependency), and to a SummaryWriter when tensorboard is importable."""
+        ep = (getattr(self.env, "extras", None) or {}).get("episode") or {}
+        keys = sorted(ep)
+        dev_keys = [k for k in keys if torch.is_tensor(ep[k])]
+        # one device -> host transfer for everything that lives on the device (mean action std + the episode means)
+        dev_vals = torch.stack([self.alg.actor_critic.std.detach().mean().float()] + [ep[k].detach().float().reshape(()) for k in dev_keys]).cpu().tolist()
+        row = {"iteration": it, "Loss/value_function": value_loss, "Loss/surrogate": surrogate, "Loss/learning_rate": self.alg.learning_rate,
+               "Policy/mean_noise_std": dev_vals[0], "Perf/total_fps": fps, "Perf/collection_time": t_collect,
+               "Perf/learning_time": t_learn, "Train/mean_reward": mean_reward, "Train/mean_episode_length": mean_len,
+               "total_timesteps": self.tot_timesteps}
+        got = dict(zip(dev_keys, dev_vals[1:]))
+        row.update({f"Episode/{k}": got[k] if k in got else float(ep[k]) for k in keys})
+        if self.writer is None:
+            os.makedirs(self.log_dir, exist_ok=True)
+            self._csv = open(os.path.join(self.log_dir, "progress.csv"), "a", buffering=1)
+            self._csv_cols = list(row)
+            if self._csv.tell() == 0:
+                self._csv.write(",".join(self._csv_cols) + "\n")
+            try:
+                from torch.utils.tensorboard import SummaryWriter
+                self.writer = SummaryWriter(log_dir=self.log_dir, flush_secs=10)
+            except Exception:
+                self.writer = False                              # tensorboard not installed: CSV only
+        self._csv.write(",".join(repr(row.get(c, "")) if not isinstance(row.get(c, ""), str) else row[c] for c in self._csv_cols) + "\n")
+        if self.writer:
+            for k, v in row.items():
+                if k != "iteration":
+                    self.writer.add_scalar(k, v, it)
+        return row
 
     def save(self, path, infos=None):
         os.makedirs(os.path.dirname(path), exist_ok=True)

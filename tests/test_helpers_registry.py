@@ -100,3 +100,23 @@ def test_logger_surface_and_headless_plot(tmp_path, capsys):
     assert os.path.isfile(path) and os.path.getsize(path) > 100
     lg.reset()
     assert not lg.state_log and not lg.rew_log
+
+
+def test_runner_scalar_log_uses_rsl_rl_tag_names(tmp_path):
+    """OnPolicyRunner._log_scalars: progress.csv with rsl_rl's TensorBoard tags as columns (tensorboard itself is optional)."""
+    import types
+    import torch
+    from legged_games_gym_amd.rl.runner import OnPolicyRunner
+    r = OnPolicyRunner.__new__(OnPolicyRunner)
+    r.log_dir, r.writer, r.device, r.tot_timesteps = str(tmp_path), None, "cpu", 98304
+    r.alg = types.SimpleNamespace(learning_rate=1e-3, actor_critic=types.SimpleNamespace(std=torch.ones(12)))
+    r.env = types.SimpleNamespace(extras={"episode": {"rew_tracking_lin_vel": torch.tensor(0.5), "rew_torques": -0.25}})
+    r._log_scalars(0, 1000, 0.1, 0.2, 0.3, -0.01, float("nan"), 12.0)
+    r._log_scalars(1, 2000, 0.1, 0.2, 0.2, -0.02, 1.5, 13.0)
+    lines = open(tmp_path / "progress.csv").read().strip().splitlines()
+    cols = lines[0].split(",")
+    for tag in ("Loss/value_function", "Loss/surrogate", "Loss/learning_rate", "Policy/mean_noise_std", "Perf/total_fps",
+                "Train/mean_reward", "Train/mean_episode_length", "Episode/rew_torques", "Episode/rew_tracking_lin_vel"):
+        assert tag in cols
+    assert len(lines) == 3 and lines[2].split(",")[cols.index("Train/mean_reward")] == "1.5"
+    assert lines[2].split(",")[cols.index("Episode/rew_torques")] == "-0.25"
