@@ -13,6 +13,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with two extra o
                   launch stream inside the timed region, against the 8 TB/s HBM peak.
   cpu_baseline -- the CPU oracle (oracle/lg_oracle.c, OpenMP over envs, all host cores of
                   this box) on a bounded sample of the same workload; rank 0, N=1 only.
+and, as extra information (N=1, anymal_c_flat; not the headline metric):
+  ppo_training -- env-steps/s of the whole PPO loop (rollout graph + kernel update), --training-iters iterations.
 """
 import argparse
 import json
