@@ -254,3 +254,14 @@ def test_resume_continues_training_on_the_kernel_update_path(tmp_path):
     assert all(float(s["step"]) == 6 * 20 for s in b.alg.optimizer.state.values())
     assert all(bool(torch.isfinite(p).all()) for p in b.alg.actor_critic.parameters())
     assert any(not torch.equal(pa, pb) for pa, pb in zip(a.alg.actor_critic.parameters(), b.alg.actor_critic.parameters()))
+
+
+@pytest.mark.parametrize("task", ["anymal_c_flat", "cassie"])
+def test_reference_style_smoke_script(task, capsys):
+    """legged_games_gym_amd/tests/test_env.py (mirror of the reference's manual smoke script): zero actions, <= 10 envs."""
+    from legged_games_gym_amd.tests.test_env import test_env as smoke_env
+    from legged_games_gym_amd.utils import get_args
+    args = get_args(["--task", task, "--headless", "--sim_device", "cuda:0", "--rl_device", "cuda:0"])
+    resets, time_outs = smoke_env(args, steps=1200)
+    assert "Done" in capsys.readouterr().out
+    assert time_outs >= 10 or resets >= 10                        # every env finished at least one 1000-step episode
