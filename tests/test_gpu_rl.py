@@ -261,8 +261,8 @@ def test_mlp_kernels_ragged_widths_and_a_single_net():
     assert not MlpTrainer([wide], [torch.randn(64, 48, device="cuda")], 64).supported
 
 
-@pytest.mark.parametrize("clipped", [1, 0])
-def test_fused_ppo_minibatch_equals_forward_loss_backward(clipped):
+@pytest.mark.parametrize("clipped,critic_obs", [(1, 48), (0, 48), (1, 45)])
+def test_fused_ppo_minibatch_equals_forward_loss_backward(clipped, critic_obs):
     """lg_ppo_minibatch (forward + PPO loss + backward in one kernel) against lg_mlp_forward -> lg_ppo_loss -> lg_mlp_backward."""
     from legged_games_gym_amd import capi
     from legged_games_gym_amd.rl.mlp_kernels import MlpTrainer
@@ -271,10 +271,11 @@ def test_fused_ppo_minibatch_equals_forward_loss_backward(clipped):
     st.compute_returns(torch.zeros(1000, 1, device="cuda"), 0.99, 0.95)
     B, A, mb = 8000, 12, 16 * 187 + 9
     ix = torch.randperm(B, device="cuda")[:mb]
-    actor, critic = _mlp(48, 12, 0), _mlp(48, 1, 1)
+    actor, critic = _mlp(48, 12, 0), _mlp(critic_obs, 1, 1)
     std = (0.7 + 0.5 * torch.rand(A, device="cuda"))
     obs = st.observations.flatten(0, 1)
-    tr = MlpTrainer([actor, critic], [obs, obs], mb)
+    cobs = obs if critic_obs == 48 else torch.randn(B, critic_obs, device="cuda")      # privileged observations of another width
+    tr = MlpTrainer([actor, critic], [obs, cobs], mb)
     p = lambda t: t.data_ptr()
     # three-call path
     mu, val = tr.forward(ix)
