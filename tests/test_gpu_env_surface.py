@@ -219,7 +219,7 @@ def test_train_then_headless_play_resumes_from_checkpoint(tmp_path, monkeypatch)
     import os
     root = tmp_path / "logs" / "flat_anymal_c"
     runs = os.listdir(root)
-    assert len(runs) == 1 and sorted(os.listdir(root / runs[0])) == ["model_0.pt", "model_1.pt"]
+    assert len(runs) == 1 and sorted(os.listdir(root / runs[0])) == ["model_0.pt", "model_1.pt", "progress.csv"]
     env2 = play(get_args(["--task", "anymal_c_flat", "--headless", "--sim_device", "cuda:0", "--rl_device", "cuda:0"]), steps=5)
     assert env2.num_envs == 50 and not env2.cfg.noise.add_noise and torch.isfinite(env2.obs_buf).all()
     # restore the registered (shared, mutated-in-place like the reference) configs for the other tests
