@@ -106,6 +106,8 @@ template <bool HF> LG_DEV HfFetch hf_fetch(const KArgs &A, float x, float y) {
     const lg_params &P = A.P;
     float inv = 1.0f / P.hf_horizontal_scale;
     float gx = (x + P.hf_border) * inv, gy = (y + P.hf_border) * inv;
+    if (!(fabsf(gx) < 1e9f)) gx = 0.0f;                 // non-finite / absurd position (the env is reset at the end of the step): no float -> int UB
+    if (!(fabsf(gy) < 1e9f)) gy = 0.0f;
     float fx = floorf(gx), fy = floorf(gy);
     int ix = (int)fx, iy = (int)fy;
     f.tx = gx - fx; f.ty = gy - fy;
@@ -516,7 +518,9 @@ template <class T, int NW = LG_STEP_WAVES> struct HeightCrew {
                     int i = min(4 * (sub + b * NV) + t, np - 1);                   // clamped: the tail re-reads a valid point
                     V3 p = quat_apply(qy, v3(A.hpts[2 * i], A.hpts[2 * i + 1], 0.0f));
                     float px = p.x + x + P.hf_border, py = p.y + y + P.hf_border;
-                    int ix = (int)(px / P.hf_horizontal_scale), iy = (int)(py / P.hf_horizontal_scale);   // .long(): truncation; int32 saturates, then clamps
+                    if (!(fabsf(px) < 1e8f)) px = 0.0f;                            // non-finite pose (reset follows): keep the conversion defined
+                    if (!(fabsf(py) < 1e8f)) py = 0.0f;
+                    int ix = (int)(px / P.hf_horizontal_scale), iy = (int)(py / P.hf_horizontal_scale);   // .long(): truncation
                     ix = min(max(ix, 0), P.hf_rows - 2); iy = min(max(iy, 0), P.hf_cols - 2);
                     const int16_t *hp = H + ix * P.hf_cols + iy;                   // rows x cols < 2^31 (checked at bind)
                     s0[b][t] = hp[0]; s1[b][t] = hp[P.hf_cols]; s2[b][t] = hp[1];
@@ -793,7 +797,9 @@ template <class T, bool NET, bool HF, int NW> struct HelperWave {
                 }
                 if (OFF) {                                         // the bodies' frames arrive from the rigid-body wave (long before, normally)
                     volatile int *flag = &sh.fk_ready;
-                    while (*flag < it + 1) {}
+                    // bounded: ~0.3 s at most, then go on with whatever is in LDS (wrong numbers beat a hung CU; the rigid-body
+                    // wave publishes the flag unconditionally every sub-step, so the bound is never reached in a correct run)
+                    for (int spin = 0; *flag < it + 1 && spin < (1 << 22); spin++) __builtin_amdgcn_s_sleep(1);
 #pragma unroll 1
                     for (int b = j; b < T::L; b += NW - 1) {
                         const float4 f0 = sh.fk[b][0][lane], f1 = sh.fk[b][1][lane], f2 = sh.fk[b][2][lane], f3 = sh.fk[b][3][lane];

@@ -16,8 +16,8 @@
  *  (2) PHYSICS HALF -- the reference delegates gym.simulate() to PhysX
  *      (closed source, absent): PARITY UNPINNED against PhysX.  This file
  *      *defines* the rigid-body step the HIP kernels must reproduce:
- *      floating-base articulated-body algorithm in world-aligned coordinates
- *      about the base origin, implicit (backward-Euler) spring-damper contacts
+ *      floating-base articulated-body algorithm in world-aligned coordinates,
+ *      every body's spatial quantities about its own joint origin, implicit (backward-Euler) spring-damper contacts
  *      and joint limits folded into the articulated inertias, implicit regularised
  *      Coulomb friction refined over two passes, semi-implicit Euler.
  *      See DESIGN.md "Physics step".
@@ -245,6 +245,8 @@ static void ground_query(const lgo_sim *s, float x, float y, float *h, v3 *n) {
     if (s->P.terrain_type == LG_TERRAIN_PLANE || !s->B.height_samples) { *h = 0.0f; *n = V(0, 0, 1); return; }
     float inv = 1.0f / s->P.hf_horizontal_scale;
     float gx = (x + s->P.hf_border) * inv, gy = (y + s->P.hf_border) * inv;
+    if (!(fabsf(gx) < 1e9f)) gx = 0.0f;            /* non-finite / absurd position: keep float -> int defined (the env resets) */
+    if (!(fabsf(gy) < 1e9f)) gy = 0.0f;
     float fx = floorf(gx), fy = floorf(gy);
     int ix = (int)fx, iy = (int)fy;
     float tx = gx - fx, ty = gy - fy;
@@ -616,6 +618,8 @@ static void get_heights(const lgo_sim *s, int e, float *out) {   /* :831-869 */
     for (int i = 0; i < P->num_height_points; i++) {
         v3 p = quat_apply(qy, V(P->height_points[i][0], P->height_points[i][1], 0.0f));
         float px = p.x + root[0] + P->hf_border, py = p.y + root[1] + P->hf_border;
+        if (!(fabsf(px) < 1e8f)) px = 0.0f;
+        if (!(fabsf(py) < 1e8f)) py = 0.0f;
         long ix = (long)(px / P->hf_horizontal_scale), iy = (long)(py / P->hf_horizontal_scale);   /* .long() truncates */
         if (ix < 0) ix = 0; if (ix > P->hf_rows - 2) ix = P->hf_rows - 2;
         if (iy < 0) iy = 0; if (iy > P->hf_cols - 2) iy = P->hf_cols - 2;

@@ -50,3 +50,58 @@ def randomize_env_params(num_envs, seed, friction_range=(0.0, 1.5), mass_range=(
     fr = buckets[rng.integers(0, 64, num_envs)]
     dm = rng.uniform(mass_range[0], mass_range[1], num_envs).astype(np.float32)
     return fr, dm
+
+
+def synth_state(robot, p, N, seed, with_heights=False, hf=None):
+    """Seeded synthetic post-sub-step state (torch tensors keyed by buffer name): random poses / velocities, sparse contact
+    forces, random episode lengths incl. time-outs.  Inputs of the G4 fixtures (tools/make_golden.py) and of the
+    decimation = 0 parity tests."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.rand(*s, generator=g)
+    n, nb, K = robot.num_dof, robot.num_bodies, robot.num_limbs
+    # half the envs are "calm" (nearly upright, slow, small commands): their total reward is positive, so the
+    # only_positive_rewards clip (legged_robot.py:205-206) is exercised on both sides
+    calm = torch.where(r(N, 1) > 0.5, 1.0, 0.02)
+    quat = torch.randn(N, 4, generator=g) * calm + (1.0 - calm) * torch.tensor([0.0, 0.0, 0.0, 1.0])
+    quat = quat / quat.norm(dim=1, keepdim=True)
+    root = torch.cat((r(N, 3) * torch.tensor([40.0, 40.0, 0.4]) + torch.tensor([0.0, 0.0, 0.4]), quat, torch.randn(N, 6, generator=g) * calm), dim=1)
+    cf = torch.randn(N, nb, 3, generator=g) * 40.0 * (r(N, nb, 1) > 0.6)
+    cf[:, 0] *= (r(N, 1) > 0.8)                       # base contact is rarer
+    cf *= (calm * calm).unsqueeze(-1)                 # calm envs touch nothing hard (forces below the 0.1 N collision threshold)
+    qd = torch.randn(N, n, generator=g) * 4.0 * calm
+    st = {
+        "root_states": root.float(), "dof_state": torch.stack((torch.randn(N * n, generator=g) * 0.8, qd.reshape(-1)), dim=1).float(),
+        "contact_forces": cf.float(), "actions": torch.randn(N, n, generator=g).float(), "last_actions": torch.randn(N, n, generator=g).float(),
+        "last_dof_vel": (qd + torch.randn(N, n, generator=g) * 4.0 * calm * calm).float(), "torques": (torch.randn(N, n, generator=g) * 30.0).float(),
+        "commands": torch.cat((r(N, 3) * 2 - 1, r(N, 1) * 6.28 - 3.14), dim=1).float() * (r(N, 1) > 0.15) * torch.sqrt(calm),
+        "feet_air_time": (r(N, K) * 0.8 * (r(N, K) > 0.3)).float(), "last_contacts": r(N, K) > 0.5,
+        "episode_length_buf": torch.randint(0, 1003, (N,), generator=g),
+    }
+    return st
+
+
+def golden_tweak(kind):
+    """Config edits shared by the G4 fixture generator (applied to the REFERENCE's config classes) and by the tests that
+    replay the fixtures (applied to this repo's config classes).  RNG consumers are switched off: the reference draws from
+    torch's global generator, the build from Philox."""
+    def tweak(cfg):
+        cfg.noise.add_noise = False
+        cfg.domain_rand.push_robots = False
+        cfg.commands.resampling_time = 1.0e6           # no resampling in the fixtures
+        if kind in ("anymal_c_rough", "a1"):           # exercise every reward term at once
+            for k in ("base_height", "dof_vel", "stand_still", "orientation", "feet_contact_forces", "dof_pos_limits", "termination"):
+                setattr(cfg.rewards.scales, k, -0.37)
+            cfg.rewards.scales.dof_vel_limits = -0.11
+            cfg.rewards.scales.torque_limits = -0.013
+            cfg.rewards.scales.stumble = -0.4
+            # (no_fly exists only on Cassie -- cassie.py:43-46 -- and is on in its registered config)
+            cfg.rewards.only_positive_rewards = False
+        if kind != "heights":                          # make_setup's default for tests without a terrain object
+            cfg.terrain.mesh_type, cfg.terrain.curriculum = "plane", False
+        if kind == "heights":
+            cfg.terrain.mesh_type, cfg.terrain.num_rows, cfg.terrain.num_cols, cfg.terrain.border_size = "heightfield", 2, 2, 5
+            cfg.terrain.curriculum = False
+        if kind.startswith("pd_"):
+            cfg.control.control_type = kind[3:]
+    return tweak

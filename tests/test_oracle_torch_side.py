@@ -1,92 +1,61 @@
-"""Pins the torch-side half of the CPU oracle (post-physics block, PD torques, actuator net) against
-G1 (reference weights through ATen's LSTM op) and G4 (torch transcriptions of the cited reference lines)."""
+"""Pins the torch-side half of the CPU oracle (post-physics block, PD torques, height sampling, actuator net) against
+fixtures produced by the reference's OWN code: G1 (reference actuator weights through ATen's LSTM operator) and G4
+(tests/golden/post_physics_<task>.npz, heights.npz, pd_torques.npz -- the reference's method bodies, extracted with ast
+from /root/reference at generation time and executed on seeded synthetic state by tools/make_golden.py; the arrays listed
+in each fixture's ``external_helper_arrays`` additionally pass through the restated isaacgym.torch_utils helpers)."""
 import os
 
 import numpy as np
 import pytest
-import torch
 
-from tests.common import make_setup
-from tests.ref_transcription import TorchSideRef, pd_torques
+from tests.common import make_setup, golden_tweak
 from oracle.oracle import OracleSim
 
-
-def synth_state(robot, p, N, seed, with_heights=False, hf=None):
-    g = torch.Generator().manual_seed(seed)
-    r = lambda *s: torch.rand(*s, generator=g)
-    n, nb, K = robot.num_dof, robot.num_bodies, robot.num_limbs
-    quat = torch.randn(N, 4, generator=g)
-    quat = quat / quat.norm(dim=1, keepdim=True)
-    root = torch.cat((r(N, 3) * torch.tensor([40.0, 40.0, 0.4]) + torch.tensor([0.0, 0.0, 0.4]), quat, torch.randn(N, 6, generator=g)), dim=1)
-    cf = torch.randn(N, nb, 3, generator=g) * 40.0 * (r(N, nb, 1) > 0.6)
-    cf[:, 0] *= (r(N, 1) > 0.8)                       # base contact is rarer
-    st = {
-        "root_states": root.float(), "dof_state": torch.stack((torch.randn(N * n, generator=g) * 0.8, torch.randn(N * n, generator=g) * 4.0), dim=1).float(),
-        "contact_forces": cf.float(), "actions": torch.randn(N, n, generator=g).float(), "last_actions": torch.randn(N, n, generator=g).float(),
-        "last_dof_vel": (torch.randn(N, n, generator=g) * 4.0).float(), "torques": (torch.randn(N, n, generator=g) * 30.0).float(),
-        "commands": torch.cat((r(N, 3) * 2 - 1, r(N, 1) * 6.28 - 3.14), dim=1).float() * (r(N, 1) > 0.15),
-        "feet_air_time": (r(N, K) * 0.8 * (r(N, K) > 0.3)).float(), "last_contacts": r(N, K) > 0.5,
-        "episode_length_buf": torch.randint(0, 1003, (N,), generator=g),
-    }
-    return st
+G4_INPUTS = ("root_states", "dof_state", "contact_forces", "actions", "last_actions", "last_dof_vel", "torques", "commands",
+             "feet_air_time", "last_contacts", "episode_length_buf")
 
 
-def load_into(o, st):
-    for k, v in st.items():
+def load_fixture_inputs(o, g, prefix="in_"):
+    for k in G4_INPUTS:
         dst = o.buf[k]
-        dst[...] = v.numpy().astype(dst.dtype).reshape(dst.shape)
+        dst[...] = g[prefix + k].astype(dst.dtype).reshape(dst.shape)
 
 
-def torch_scales(names, p):
-    from legged_games_gym_amd import capi
-    return {n: float(p.reward_scale[capi.REWARD_TERMS.index(n)]) for n in names}
-
-
-@pytest.mark.parametrize("task", ["anymal_c_flat", "cassie", "anymal_c_rough"])
-def test_post_physics_matches_transcription(task, oracle_lib):
-    N = 257
-
-    def tweak(cfg):
-        cfg.noise.add_noise = False
-        cfg.domain_rand.push_robots = False
-        cfg.commands.resampling_time = 1.0e6           # no resampling in this test
-        if task == "anymal_c_rough":                   # exercise every reward term at once
-            for k in ("base_height", "dof_vel", "stand_still", "orientation", "feet_contact_forces", "dof_pos_limits", "termination"):
-                setattr(cfg.rewards.scales, k, -0.37)
-            cfg.rewards.scales.dof_vel_limits = -0.11
-            cfg.rewards.scales.torque_limits = -0.013
-            cfg.rewards.scales.stumble = -0.4
-            cfg.rewards.scales.no_fly = 0.21
-            cfg.rewards.only_positive_rewards = False
-    cfg, robot, p, names, model, w = make_setup(task, N, tweak=tweak)
+@pytest.mark.parametrize("task", ["anymal_c_flat", "cassie", "anymal_c_rough", "a1"])
+def test_post_physics_matches_reference_fixture(task, oracle_lib, golden_dir):
+    g = np.load(os.path.join(golden_dir, f"post_physics_{task}.npz"))
+    N = g["in_root_states"].shape[0]
+    cfg, robot, p, names, model, w = make_setup(task, N, tweak=golden_tweak(task))
     p.decimation = 0                                   # post-physics only: contact forces / torques are inputs
+    assert names == [str(n) for n in g["reward_names"]]                               # alphabetical, zero scales dropped (:583-607)
+    from legged_games_gym_amd import capi
+    np.testing.assert_allclose([p.reward_scale[capi.REWARD_TERMS.index(n)] for n in names], g["reward_scales_dt"], rtol=1e-6)
+    assert p.max_episode_length == int(g["max_episode_length"]) and abs(p.dt_policy - float(g["dt"])) < 1e-9
     o = OracleSim(p, model, robot, w)
-    st = synth_state(robot, p, N, seed=hash(task) % 1000)
-    load_into(o, st)
-    ref = TorchSideRef(cfg, robot, p, torch_scales(names, p), st)
-    if cfg.terrain.measure_heights:
-        ref.num_height_points = p.num_height_points
-    ref.post_physics_step()
-    # keep resets out of the comparison of post-reset quantities: compare rewards/termination for all, state only for survivors
-    o.step(st["actions"].numpy(), 5)
-    keep = ~ref.reset_buf.numpy()
-    assert keep.sum() > 20 and (~keep).sum() > 5
-    np.testing.assert_array_equal(o.buf["reset_buf"].astype(bool), ref.reset_buf.numpy())
-    np.testing.assert_array_equal(o.buf["time_out_buf"].astype(bool), ref.time_out_buf.numpy())
-    np.testing.assert_allclose(o.buf["rew_buf"], ref.rew_buf.numpy(), rtol=2e-5, atol=2e-6)
-    np.testing.assert_allclose(o.buf["base_lin_vel"], ref.base_lin_vel.numpy(), rtol=1e-5, atol=1e-6)
-    np.testing.assert_allclose(o.buf["projected_gravity"], ref.projected_gravity.numpy(), rtol=1e-5, atol=1e-6)
+    load_fixture_inputs(o, g)
+    o.step(g["in_actions"], 5)
+    # rewards / termination for every env; post-reset quantities only for the survivors (reset_idx draws from the RNG)
+    rs = g["reset_buf"].astype(bool)
+    keep = ~rs
+    assert keep.sum() > 20 and rs.sum() > 5
+    np.testing.assert_array_equal(o.buf["reset_buf"].astype(bool), rs)
+    np.testing.assert_array_equal(o.buf["time_out_buf"].astype(bool), g["time_out_buf"].astype(bool))
+    np.testing.assert_allclose(o.buf["rew_buf"], g["rew_buf"], rtol=2e-5, atol=2e-6)
+    if cfg.rewards.only_positive_rewards:              # the clip at zero acted on some envs and not on others
+        assert (g["rew_buf"] > 0).sum() > 10 and (g["rew_buf"] == 0).sum() > 10
+    np.testing.assert_allclose(o.buf["base_lin_vel"], g["base_lin_vel"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(o.buf["base_ang_vel"], g["base_ang_vel"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(o.buf["projected_gravity"], g["projected_gravity"], rtol=1e-5, atol=1e-6)
     for i, nme in enumerate(names):                    # per-term episode sums (zeroed for reset envs)
-        np.testing.assert_allclose(o.buf["episode_sums"][i][keep], ref.episode_sums[nme].numpy()[keep], rtol=2e-5, atol=2e-6, err_msg=nme)
-    np.testing.assert_allclose(o.buf["obs_buf"][keep], ref.obs_buf.numpy()[keep], rtol=1e-5, atol=2e-6)
-    np.testing.assert_allclose(o.buf["feet_air_time"][keep], ref.feet_air_time.numpy()[keep], rtol=1e-6, atol=1e-7)
-    np.testing.assert_array_equal(o.buf["last_contacts"][keep].astype(bool), ref.last_contacts.numpy()[keep])
-    np.testing.assert_allclose(o.buf["last_actions"], st["actions"].numpy())     # :132 also for reset envs
-    np.testing.assert_allclose(o.buf["commands"][keep], ref.commands.numpy()[keep], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(o.buf["episode_sums"][i][keep], g["episode_sums"][i][keep], rtol=2e-5, atol=2e-6, err_msg=nme)
+    np.testing.assert_allclose(o.buf["obs_buf"][keep], g["obs_buf"][keep], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(o.buf["feet_air_time"][keep], g["feet_air_time"][keep], rtol=1e-6, atol=1e-7)
+    np.testing.assert_array_equal(o.buf["last_contacts"][keep].astype(bool), g["last_contacts"][keep].astype(bool))
+    np.testing.assert_allclose(o.buf["last_actions"], g["in_actions"])            # :132 also for reset envs
+    np.testing.assert_allclose(o.buf["commands"][keep], g["commands"][keep], rtol=1e-5, atol=1e-6)
     # extras["episode"]: mean over reset envs of the episode sums / max_episode_length_s (:179-183)
-    rs = ref.reset_buf.numpy()
     for i, nme in enumerate(names):
-        want = ref.episode_sums[nme].numpy()[rs].mean() / cfg.env.episode_length_s
+        want = g["episode_sums"][i][rs].mean() / cfg.env.episode_length_s
         assert abs(o.buf["episode_means"][i] - want) < 2e-5 + 2e-5 * abs(want), nme
     # reset envs: freshly written state, zero dof_vel, obs built from it with the STALE base-frame quantities (Q7)
     idx = np.nonzero(rs)[0]
@@ -94,74 +63,52 @@ def test_post_physics_matches_transcription(task, oracle_lib):
     q0 = np.array(list(p.default_dof_pos)[:12])
     ratio = o.dof_pos[idx][:, np.abs(q0) > 1e-6] / q0[np.abs(q0) > 1e-6]
     assert ratio.min() >= 0.5 and ratio.max() <= 1.5
-    np.testing.assert_allclose(o.buf["obs_buf"][idx][:, 0:3], np.clip(ref.base_lin_vel.numpy()[idx] * 2.0, -100, 100), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(o.buf["obs_buf"][idx][:, 0:3], np.clip(g["base_lin_vel"][idx] * 2.0, -100, 100), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(o.buf["obs_buf"][idx][:, 24:36], 0.0)
 
 
-def test_heights_match_transcription(oracle_lib):
-    """_get_heights :831-869 on a synthetic int16 height field (min of 3 samples, truncation, border, yaw-only)."""
-    N = 64
-    rng = np.random.default_rng(5)
+def heights_setup(g, N):
+    """The oracle-side twin of the heights.npz generator set-up: a 2 x 2-tile field whose samples come from the fixture."""
     from legged_games_gym_amd.utils.terrain import Terrain
-    from legged_games_gym_amd.envs import configs
-    tc = configs.AnymalCRoughCfg().terrain
-    tc.mesh_type, tc.num_rows, tc.num_cols, tc.border_size = "heightfield", 2, 2, 5
+    from tests.common import TASK_CFG
+    mine = TASK_CFG["anymal_c_rough"]()
+    golden_tweak("heights")(mine)
     np.random.seed(3)
-    terr = Terrain(tc, N)
-    terr.height_field_raw[:] = rng.integers(-60, 60, terr.height_field_raw.shape).astype(np.int16)
-
-    def tweak(cfg):
-        cfg.terrain.mesh_type, cfg.terrain.num_rows, cfg.terrain.num_cols, cfg.terrain.border_size = "heightfield", 2, 2, 5
-        cfg.terrain.curriculum = False
-        cfg.noise.add_noise = False
-        cfg.domain_rand.push_robots = False
-        cfg.commands.resampling_time = 1.0e6
-    cfg, robot, p, names, model, w = make_setup("anymal_c_rough", N, plane=False, terrain=terr, tweak=tweak)
+    terr = Terrain(mine.terrain, N)
+    terr.height_field_raw[:] = g["height_samples"]
+    cfg, robot, p, names, model, w = make_setup("anymal_c_rough", N, plane=False, terrain=terr, tweak=golden_tweak("heights"))
     p.decimation = 0
+    return terr, cfg, robot, p, names, model, w
+
+
+def test_heights_match_reference_fixture(oracle_lib, golden_dir):
+    """_get_heights :831-869 on a synthetic int16 height field (min of 3 samples, truncation, border, yaw-only)."""
+    g = np.load(os.path.join(golden_dir, "heights.npz"))
+    N = g["in_root_states"].shape[0]
+    terr, cfg, robot, p, names, model, w = heights_setup(g, N)
     o = OracleSim(p, model, robot, w)
     o.set_terrain(terr.heightsamples, terr.env_origins)
-    st = synth_state(robot, p, N, seed=9)
-    st["root_states"][:, 0:2] = torch.rand(N, 2) * 30.0 - 4.0      # some points fall outside -> index clipping
-    st["contact_forces"][:] = 0
-    st["episode_length_buf"][:] = 3
-    load_into(o, st)
-    ref = TorchSideRef(cfg, robot, p, torch_scales(names, p), st)
-    ref.num_height_points = p.num_height_points
-    ref.height_samples = torch.from_numpy(terr.heightsamples.astype(np.int64))
-    y = torch.tensor(cfg.terrain.measured_points_y); x = torch.tensor(cfg.terrain.measured_points_x)
-    gx, gy = torch.meshgrid(x, y, indexing="ij")
-    pts = torch.zeros(N, gx.numel(), 3); pts[:, :, 0] = gx.flatten(); pts[:, :, 1] = gy.flatten()
-    ref.height_points = pts
-    ref.post_physics_step()
-    o.step(st["actions"].numpy(), 5)
-    mism = np.abs(o.buf["measured_heights"] - ref.measured_heights.numpy()) > 1e-6
+    load_fixture_inputs(o, g)
+    o.step(g["in_actions"], 5)
+    assert not g["reset_buf"].any() and np.abs(g["measured_heights"]).max() > 0.2
+    mism = np.abs(o.buf["measured_heights"] - g["measured_heights"]) > 1e-6
     assert mism.mean() < 2e-3, mism.mean()          # only points within 1 ulp of a cell edge may truncate differently
     ok = ~mism.any(axis=1)
-    np.testing.assert_allclose(o.buf["obs_buf"][ok], ref.obs_buf.numpy()[ok], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(o.buf["obs_buf"][ok], g["obs_buf"][ok], rtol=1e-5, atol=2e-6)
 
 
 @pytest.mark.parametrize("ctrl", ["P", "V", "T"])
-def test_pd_torques_match_transcription(ctrl, oracle_lib):
-    """_compute_torques :371-395 through one oracle step with the physics disabled by zero gravity... the torque
-    buffer after a step holds the LAST sub-step's torques, so use decimation=1 and compare against the pre-step state."""
-    N = 33
-
-    def tweak(cfg):
-        cfg.control.control_type = ctrl
-        cfg.noise.add_noise = False
-    cfg, robot, p, names, model, w = make_setup("cassie", N, tweak=tweak)
+def test_pd_torques_match_reference_fixture(ctrl, oracle_lib, golden_dir):
+    """_compute_torques :371-395 through one oracle step: the torque buffer after a step holds the LAST sub-step's torques,
+    so use decimation=1 (airborne robots) and compare against the reference's torques for the pre-step state."""
+    g = np.load(os.path.join(golden_dir, "pd_torques.npz"))
+    N = g[ctrl + "_actions"].shape[0]
+    cfg, robot, p, names, model, w = make_setup("cassie", N, tweak=golden_tweak("pd_" + ctrl))
     p.decimation = 1
     o = OracleSim(p, model, robot, w)
-    st = synth_state(robot, p, N, seed=21)
-    st["root_states"][:, 2] = 5.0                      # airborne: no contact
-    st["episode_length_buf"][:] = 1
-    load_into(o, st)
-    act = st["actions"] * 2.0
-    dof = st["dof_state"].view(N, 12, 2)
-    want = pd_torques(cfg, torch.tensor(list(p.p_gains)[:12]), torch.tensor(list(p.d_gains)[:12]), torch.tensor(list(p.default_dof_pos)[:12]),
-                      torch.tensor(robot.dof_effort, dtype=torch.float), act, dof[..., 0], dof[..., 1], st["last_dof_vel"], cfg.sim.dt)
-    o.step(act.numpy(), 7)
-    np.testing.assert_allclose(o.buf["torques"], want.numpy(), rtol=1e-5, atol=1e-5)
+    load_fixture_inputs(o, g, prefix=ctrl + "_in_")
+    o.step(g[ctrl + "_actions"], 7)
+    np.testing.assert_allclose(o.buf["torques"], g[ctrl + "_torques"], rtol=1e-5, atol=1e-5)
     with pytest.raises(NameError):
         make_setup("cassie", 4, tweak=lambda c: setattr(c.control, "control_type", "X"))
 
@@ -194,10 +141,12 @@ def test_actuator_in_step_uses_pos_err_and_vel(oracle_lib):
     cfg, robot, p, names, model, w = make_setup("anymal_c_flat", N, tweak=lambda c: setattr(c.noise, "add_noise", False))
     p.decimation = 1
     o = OracleSim(p, model, robot, w)
+    from tests.common import synth_state
     st = synth_state(robot, p, N, seed=4)
     st["root_states"][:, 2] = 5.0
     st["episode_length_buf"][:] = 1
-    load_into(o, st)
+    for k, v in st.items():
+        o.buf[k][...] = v.numpy().astype(o.buf[k].dtype).reshape(o.buf[k].shape)
     dof = st["dof_state"].view(N, 12, 2).numpy()
     q0 = np.array(list(p.default_dof_pos)[:12], np.float32)
     act = (st["actions"] * 3).numpy()

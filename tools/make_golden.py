@@ -10,7 +10,22 @@ G2 configs.json      -- ``class_to_dict`` of the reference's OWN config classes 
                         (legged_gym/envs/base/{base_config,legged_robot_config}.py, anymal_c_*_config.py,
                         cassie_config.py) under a synthetic ``legged_gym`` package (they import nothing else).
 G3 models.json       -- body / DOF / shape counts, masses, foot positions derived from the reference URDFs.
+G4 post_physics_<task>.npz, heights.npz, pd_torques.npz
+                     -- inputs + outputs of the reference's OWN torch-side code.  The method bodies are taken from the
+                        reference source files with ``ast`` at generation time (nothing is copied into this repo) and executed
+                        on seeded synthetic state: ``LeggedRobot._parse_cfg / _prepare_reward_function / _init_height_points /
+                        _post_physics_step_callback / _resample_commands / check_termination / compute_reward /
+                        compute_observations / _get_heights / _compute_torques`` and all ``_reward_*``
+                        (legged_gym/envs/base/legged_robot.py), ``Cassie._reward_no_fly`` (envs/cassie/cassie.py),
+                        ``quat_apply_yaw`` / ``wrap_to_pi`` (utils/math.py), ``class_to_dict`` (utils/helpers.py), with the
+                        reference's own config classes.  None of them touches isaacgym except through five
+                        ``isaacgym.torch_utils`` helpers (quat_rotate_inverse, quat_apply, normalize, torch_rand_float,
+                        get_axis_params), which are absent and therefore RESTATED below from their standard definitions:
+                        arrays that depend on them are listed under ``external_helper_arrays`` in each fixture.
+                        Robot-derived index / limit tensors (feet_indices, dof_pos_limits, ...) come from this repo's model
+                        compiler (pinned by G3) and are stored as inputs.
 """
+import ast
 import importlib.util
 import json
 import os
@@ -143,5 +158,208 @@ def g3():
     print("G3 models.json:", {k: (v["num_bodies"], v["num_dof"], v["num_shapes"], round(v["total_mass"], 5)) for k, v in out.items()})
 
 
+# ----------------------------------------------------------------------------- G4
+def _ref_functions(rel, class_name, namespace, want=None):
+    """name -> function object for every ``def`` of ``class_name`` (or of the module when None) in a reference source file.
+    The file is parsed, never imported; each def is compiled on its own inside ``namespace``."""
+    path = os.path.join(REF, rel)
+    tree = ast.parse(open(path).read(), filename=path)
+    body = tree.body
+    if class_name is not None:
+        body = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == class_name).body
+    out = {}
+    for node in body:
+        if isinstance(node, ast.FunctionDef) and (want is None or want(node.name)):
+            node.decorator_list, node.returns = [], None
+            for a in node.args.args + node.args.kwonlyargs:
+                a.annotation = None                    # type hints name classes that are not importable here
+            scope = dict(namespace)
+            exec(compile(ast.Module(body=[node], type_ignores=[]), path, "exec"), scope)
+            fn = scope[node.name]
+            fn.__globals__.update(namespace)          # see the shared helpers (and each other) at call time
+            out[node.name] = fn
+    return out
+
+
+def _external_helpers():
+    """[EXTERNAL, absent] isaacgym.torch_utils -- standard definitions (quaternions xyzw), restated."""
+    import torch
+
+    def quat_rotate_inverse(q, v):
+        q_w = q[:, -1]
+        q_vec = q[:, :3]
+        a = v * (2.0 * q_w ** 2 - 1.0).unsqueeze(-1)
+        b = torch.cross(q_vec, v, dim=-1) * q_w.unsqueeze(-1) * 2.0
+        c = q_vec * torch.bmm(q_vec.view(q.shape[0], 1, 3), v.view(q.shape[0], 3, 1)).squeeze(-1) * 2.0
+        return a - b + c
+
+    def quat_apply(a, b):
+        shape = b.shape
+        a = a.reshape(-1, 4)
+        b = b.reshape(-1, 3)
+        xyz = a[:, :3]
+        t = xyz.cross(b, dim=-1) * 2
+        return (b + a[:, 3:] * t + xyz.cross(t, dim=-1)).view(shape)
+
+    def normalize(x, eps: float = 1e-9):
+        return x / x.norm(p=2, dim=-1).clamp(min=eps, max=None).unsqueeze(-1)
+
+    def torch_rand_float(lower, upper, shape, device):
+        return (upper - lower) * torch.rand(*shape, device=device) + lower
+
+    return {"quat_rotate_inverse": quat_rotate_inverse, "quat_apply": quat_apply, "normalize": normalize, "torch_rand_float": torch_rand_float}
+
+
+def build_reference_env(task, N, state, tweak):
+    """A plain object carrying the reference's own methods (extracted with ast) and config, filled from ``state``."""
+    import torch
+    from tests.common import TASK_CFG
+    from legged_games_gym_amd.utils.model_compiler import load_model
+    ns = {"torch": torch, "np": np}
+    ns.update(_external_helpers())
+    ns.update(_ref_functions("legged_gym/utils/math.py", None, ns, lambda k: k in ("quat_apply_yaw", "wrap_to_pi")))
+    ns.update(_ref_functions("legged_gym/utils/helpers.py", None, ns, lambda k: k == "class_to_dict"))
+    keep = _ref_functions("legged_gym/envs/base/legged_robot.py", "LeggedRobot", ns, lambda k: k.startswith("_reward_") or k in (
+        "_parse_cfg", "_prepare_reward_function", "_init_height_points", "_post_physics_step_callback", "_resample_commands",
+        "check_termination", "compute_reward", "compute_observations", "_get_heights", "_compute_torques"))
+    if task == "cassie":
+        keep.update(_ref_functions("legged_gym/envs/cassie/cassie.py", "Cassie", ns, lambda k: k == "_reward_no_fly"))
+    Ref = type("ReferenceLeggedRobotMethods", (), keep)
+    env = Ref()
+    ref_cfgs = load_reference_configs()
+    env.cfg = ref_cfgs[task][0]()                       # the reference's own config class
+    tweak(env.cfg)
+    mine = TASK_CFG[task]()
+    robot = load_model(mine.asset.file)                 # robot tables: this repo's model compiler (G3)
+    env.sim_params = types.SimpleNamespace(dt=env.cfg.sim.dt)
+    env.device, env.num_envs = "cpu", N
+    env._parse_cfg(env.cfg)
+    n = robot.num_dof
+    for k, v in state.items():
+        setattr(env, k, v.clone())
+    env.dof_pos = env.dof_state.view(N, n, 2)[..., 0]
+    env.dof_vel = env.dof_state.view(N, n, 2)[..., 1]
+    env.base_quat = env.root_states[:, 3:7].clone()
+    env.base_lin_vel, env.base_ang_vel, env.projected_gravity = torch.zeros(N, 3), torch.zeros(N, 3), torch.zeros(N, 3)
+    env.gravity_vec = torch.tensor([0.0, 0.0, -1.0]).repeat(N, 1)
+    env.forward_vec = torch.tensor([1.0, 0.0, 0.0]).repeat(N, 1)
+    env.rew_buf = torch.zeros(N)
+    env.common_step_counter = 0
+    env.add_noise = False
+    env.measured_heights = 0
+    s = env.obs_scales
+    env.commands_scale = torch.tensor([s.lin_vel, s.lin_vel, s.ang_vel])
+    # robot-derived tensors (Isaac Gym asset queries in the reference, legged_robot.py:299-314, 696-702, 564-581)
+    env.feet_indices = torch.tensor(robot.bodies_matching(env.cfg.asset.foot_name), dtype=torch.long)
+    env.penalised_contact_indices = torch.tensor([b for s_ in env.cfg.asset.penalize_contacts_on for b in robot.bodies_matching(s_)], dtype=torch.long)
+    env.termination_contact_indices = torch.tensor([b for s_ in env.cfg.asset.terminate_after_contacts_on for b in robot.bodies_matching(s_)], dtype=torch.long)
+    lo, hi = torch.tensor(robot.dof_lower, dtype=torch.float), torch.tensor(robot.dof_upper, dtype=torch.float)
+    m, r = (lo + hi) / 2, hi - lo
+    env.dof_pos_limits = torch.stack((m - 0.5 * r * env.cfg.rewards.soft_dof_pos_limit, m + 0.5 * r * env.cfg.rewards.soft_dof_pos_limit), dim=1)
+    env.dof_vel_limits = torch.tensor(robot.dof_velocity, dtype=torch.float)
+    env.torque_limits = torch.tensor(robot.dof_effort, dtype=torch.float)
+    env.default_dof_pos = torch.tensor([env.cfg.init_state.default_joint_angles[k] for k in robot.dof_names], dtype=torch.float).unsqueeze(0)
+    kp, kd = torch.zeros(n), torch.zeros(n)
+    for i, name in enumerate(robot.dof_names):
+        for key in env.cfg.control.stiffness.keys():
+            if key in name:
+                kp[i], kd[i] = env.cfg.control.stiffness[key], env.cfg.control.damping[key]
+    env.p_gains, env.d_gains = kp, kd
+    env._prepare_reward_function()
+    if env.cfg.terrain.measure_heights:
+        env.height_points = env._init_height_points()
+    return env, robot, ns
+
+
+def reference_post_physics(env, ns):
+    """The statement order of LeggedRobot.post_physics_step (legged_robot.py:106-137) around the reference's own methods;
+    the simulator refresh calls and reset_idx (RNG, sim writes) are left out -- reset envs are excluded by the tests."""
+    import torch
+    env.episode_length_buf += 1
+    env.common_step_counter += 1
+    env.base_quat[:] = env.root_states[:, 3:7]
+    env.base_lin_vel[:] = ns["quat_rotate_inverse"](env.base_quat, env.root_states[:, 7:10])
+    env.base_ang_vel[:] = ns["quat_rotate_inverse"](env.base_quat, env.root_states[:, 10:13])
+    env.projected_gravity[:] = ns["quat_rotate_inverse"](env.base_quat, env.gravity_vec)
+    env._post_physics_step_callback()
+    env.check_termination()
+    env.compute_reward()
+    env.compute_observations()
+    c = env.cfg.normalization.clip_observations          # LeggedRobot.step :100-101
+    env.obs_buf = torch.clip(env.obs_buf, -c, c)
+
+
+G4_INPUT_KEYS = ("root_states", "dof_state", "contact_forces", "actions", "last_actions", "last_dof_vel", "torques", "commands",
+                 "feet_air_time", "last_contacts", "episode_length_buf")
+
+
+def g4():
+    import torch
+    from tests.common import synth_state, golden_tweak, TASK_CFG
+    from legged_games_gym_amd.utils.model_compiler import load_model
+    ext = ["base_lin_vel", "base_ang_vel", "projected_gravity", "obs_buf", "commands", "measured_heights", "rew_buf", "episode_sums"]
+    for task, seed in (("anymal_c_flat", 101), ("cassie", 202), ("anymal_c_rough", 303), ("a1", 404)):
+        N = 257
+        robot = load_model(TASK_CFG[task]().asset.file)
+        st = synth_state(robot, None, N, seed=seed)
+        env, robot, ns = build_reference_env(task, N, st, golden_tweak(task))
+        reference_post_physics(env, ns)
+        names = list(env.reward_scales.keys())
+        out = {"in_" + k: st[k].numpy() for k in G4_INPUT_KEYS}
+        out.update(reset_buf=env.reset_buf.numpy(), time_out_buf=env.time_out_buf.numpy(), rew_buf=env.rew_buf.numpy(),
+                   base_lin_vel=env.base_lin_vel.numpy(), base_ang_vel=env.base_ang_vel.numpy(), projected_gravity=env.projected_gravity.numpy(),
+                   obs_buf=env.obs_buf.numpy(), feet_air_time=env.feet_air_time.numpy(), last_contacts=env.last_contacts.numpy(),
+                   commands=env.commands.numpy(), episode_sums=np.stack([env.episode_sums[k].numpy() for k in names]),
+                   reward_names=np.array(names), reward_scales_dt=np.array([env.reward_scales[k] for k in names], dtype=np.float64),
+                   max_episode_length=np.float64(env.max_episode_length), dt=np.float64(env.dt),
+                   external_helper_arrays=np.array(ext), seed=seed)
+        np.savez_compressed(os.path.join(OUT, f"post_physics_{task}.npz"), **out)
+        print(f"G4 post_physics_{task}.npz: {len(names)} reward terms, resets {int(env.reset_buf.sum())}/{N}, |rew| max {float(env.rew_buf.abs().max()):.4f}")
+
+    # _get_heights on a random int16 height field (points outside the field exercise the index clipping)
+    from legged_games_gym_amd.utils.terrain import Terrain
+    task, N = "anymal_c_rough", 64
+    tw = golden_tweak("heights")
+    mine = TASK_CFG[task](); tw(mine)
+    np.random.seed(3)
+    terr = Terrain(mine.terrain, N)
+    rng = np.random.default_rng(5)
+    terr.height_field_raw[:] = rng.integers(-60, 60, terr.height_field_raw.shape).astype(np.int16)
+    robot = load_model(mine.asset.file)
+    st = synth_state(robot, None, N, seed=9)
+    st["root_states"][:, 0:2] = torch.rand(N, 2, generator=torch.Generator().manual_seed(1)) * 30.0 - 4.0
+    st["contact_forces"][:] = 0
+    st["episode_length_buf"][:] = 3
+    env, robot, ns = build_reference_env(task, N, st, tw)
+    env.height_samples = torch.from_numpy(terr.heightsamples.astype(np.int64))
+    env.terrain = types.SimpleNamespace(cfg=env.cfg.terrain)
+    reference_post_physics(env, ns)
+    out = {"in_" + k: st[k].numpy() for k in G4_INPUT_KEYS}
+    out.update(height_samples=terr.heightsamples, terrain_origins=terr.env_origins, measured_heights=env.measured_heights.numpy(),
+               obs_buf=env.obs_buf.numpy(), reset_buf=env.reset_buf.numpy(), external_helper_arrays=np.array(ext))
+    np.savez_compressed(os.path.join(OUT, "heights.npz"), **out)
+    print("G4 heights.npz: field", terr.heightsamples.shape, "heights range", float(env.measured_heights.min()), float(env.measured_heights.max()))
+
+    # _compute_torques (P / V / T) on Cassie
+    out = {}
+    for ctrl in ("P", "V", "T"):
+        N = 33
+        robot = load_model(TASK_CFG["cassie"]().asset.file)
+        st = synth_state(robot, None, N, seed=21)
+        st["root_states"][:, 2] = 5.0
+        st["episode_length_buf"][:] = 1
+        env, robot, ns = build_reference_env("cassie", N, st, golden_tweak("pd_" + ctrl))
+        act = st["actions"] * 2.0
+        tau = env._compute_torques(act)
+        for k in G4_INPUT_KEYS:
+            out[f"{ctrl}_in_{k}"] = st[k].numpy()
+        out[f"{ctrl}_actions"] = act.numpy()
+        out[f"{ctrl}_torques"] = tau.numpy()
+    np.savez_compressed(os.path.join(OUT, "pd_torques.npz"), **out)
+    print("G4 pd_torques.npz: |tau| max", {c: float(np.abs(out[c + "_torques"]).max()) for c in ("P", "V", "T")})
+
+
 if __name__ == "__main__":
-    g2(); g1(); g3()
+    which = sys.argv[1:] or ["g2", "g1", "g3", "g4"]
+    for w in which:
+        {"g1": g1, "g2": g2, "g3": g3, "g4": g4}[w]()
