@@ -4,32 +4,42 @@
 A "step" = one policy step of every env on this rank: random-init actor MLP
 [48,128,64,32,12] forward + Gaussian sampling (rsl_rl ActorCritic.act) followed by
 LeggedRobot.step (4 x [actuator net -> rigid-body step] + post-physics), inputs resident
-in HBM.  One process per GPU (RANK/LOCAL_RANK/WORLD_SIZE from the env); envs shard with no
-data-path collective, so scaling is weak; the only collectives are the timing barrier / max.
+in HBM.  One process per GPU; envs shard with no data-path collective in the rollout, so scaling is weak.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     -- the fused step kernel: algorithmic bytes (4022 B/env-step on
-                  flat ANYmal) x envs / mean kernel duration from HIP events recorded on the
-                  launch stream inside the timed region, against the 8 TB/s HBM peak.
-  cpu_baseline -- the CPU oracle (oracle/lg_oracle.c, OpenMP over envs, all host cores of
-                  this box) on a bounded sample of the same workload; rank 0, N=1 only.
-and, as extra information (N=1, anymal_c_flat; not the headline metric):
-  ppo_training -- env-steps/s of the whole PPO loop (rollout graph + kernel update), --training-iters iterations.
+Launching: `python bench.py --gpus N ...` -- for N > 1 without a torch.distributed environment the parent (which never
+touches a GPU) starts N worker processes itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*, backend nccl = RCCL);
+under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` the workers are already there.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
+  roofline     -- the fused step kernel: algorithmic bytes (4022 B/env-step on flat ANYmal) x envs / mean kernel
+                  duration from HIP events recorded on the launch stream around the timed graph replays themselves, against
+                  the 8 TB/s HBM peak; and the second ratio SURVEY 8(d) asks for: counted fp32 FLOPs (tools/flop_count.py)
+                  per second against the 157.3 TFLOP/s fp32 vector peak.
+  cpu_baseline -- the CPU oracle (oracle/lg_oracle.c, OpenMP over envs, all host cores of this box) on a bounded sample of
+                  the same workload; rank 0, N=1 only.
+  ppo_training -- env-steps/s of the whole PPO loop (rollout + update).  At N > 1 this is the leg that carries the
+                  collectives north_star names (all-gather of [returns || advantages], gradient all-reduce, mean-KL
+                  all-reduce, rl/ppo.py); `rccl_ranks` is the world size as counted by a real all-reduce on the device.
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
 REPO = os.path.dirname(os.path.realpath(__file__))
 sys.path.insert(0, REPO)
 
-BYTES_PER_ENV_STEP = {"anymal_c_flat": 4022, "anymal_c_rough": 4762, "cassie": 1442}   # SURVEY.md 8(d)
+BYTES_PER_ENV_STEP = {"anymal_c_flat": 4022, "anymal_c_rough": 4762, "cassie": 1442, "a1": 1690, "anymal_b": 4762}   # SURVEY.md 8(d)
 HBM_PEAK_GBS = 8000.0                                                                 # MI355X_MICROARCH.md
+FP32_VECTOR_PEAK_TFLOPS = 157.3                                                       # MI355X_MICROARCH.md (non-matrix fp32)
+PMC_SUMMARY = os.path.join(REPO, "profiles", "r02_pmc_summary.json")
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
@@ -39,21 +49,74 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--policy", choices=["auto", "fused", "torch"], default="auto",
-                    help="auto: fused MFMA actor kernel for narrow nets (hidden <= 128, the flat config), torch/hipBLASLt otherwise")
+                    help="auto / fused: the MFMA actor kernels (inside the step kernel for the flat actor); torch: torch ops / hipBLASLt")
     ap.add_argument("--torch-policy", action="store_true", help="same as --policy torch")
     ap.add_argument("--graph-steps", type=int, default=20, help="policy steps captured per HIP-graph replay (clamped to a divisor of --steps and --warmup)")
     ap.add_argument("--no-fused-step", action="store_true", help="keep actor kernel and step kernel separate (lg_policy_act + lg_step)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one captured HIP graph per step")
-    ap.add_argument("--training-iters", type=int, default=100, help="PPO iterations timed for the extra ppo_training object (0 = skip; N=1, anymal_c_flat only)")
-    ap.add_argument("--event-steps", type=int, default=200, help="eager steps timed with HIP events for the roofline object")
-    a = ap.parse_args()
+    ap.add_argument("--training-iters", type=int, default=-1, help="PPO iterations timed for the ppo_training object (0 = skip; -1 = 100 for anymal_c_flat, 20 otherwise)")
+    ap.add_argument("--min-timed-ms", type=float, default=50.0, help="a timed region shorter than this is repeated and the median reported")
+    ap.add_argument("--event-steps", type=int, default=200, help="steps timed with HIP events for the step-kernel-only graph (tasks whose timed graph also holds the actor kernel)")
+    return ap.parse_args()
 
+
+def spawn_workers(a):
+    """`python bench.py --gpus N` without a launcher: N worker processes, one per GPU, started BEFORE anything touches a GPU."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.realpath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        while procs:
+            for p in list(procs):
+                code = p.poll()
+                if code is None:
+                    continue
+                procs.remove(p)
+                if code != 0:
+                    rc = rc or code
+                    for q in procs:          # a dead rank leaves the others in a collective: stop them (exact PIDs)
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for q in procs:
+            q.kill()
+    return rc
+
+
+def main():
+    a = parse_args()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(spawn_workers(a))
+    worker(a)
+
+
+def workload_text(task, env, pol, num_envs):
+    cfg = env.cfg
+    terrain = "plane" if cfg.terrain.mesh_type in (None, "none", "plane") else \
+        f"{env.terrain.tot_rows}x{env.terrain.tot_cols} int16 curriculum height field ({cfg.terrain.mesh_type})"
+    ctrl = "actuator-net torques" if getattr(cfg.control, "use_actuator_network", False) else f"PD control ({cfg.control.control_type})"
+    sc = "self-collision ON (asset.self_collisions = 0)" if getattr(env, "self_collision_modelled", False) else \
+        ("self-collision requested by the config but NOT modelled" if int(getattr(cfg.asset, "self_collisions", 1)) == 0 else "self-collision off (as configured)")
+    return (f"{task}, {num_envs} envs/GPU, {terrain}, {ctrl}, {sc}, random-init policy "
+            f"{[env.num_obs] + list(pol['actor_hidden_dims']) + [env.num_actions]} rollout (act = mu + sigma*eps), "
+            "fixed command (0.5,0,0), obs noise + friction/mass randomisation + pushes on")
+
+
+def worker(a):
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -66,6 +129,12 @@ def main():
             dist.init_process_group(backend)
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
+    coll_dev = dev if (world == 1 or backend == "nccl") else torch.device("cpu")
+    ranks_seen = 1
+    if world > 1:                       # did the collective library see N ranks?  one real all-reduce answers it
+        ones = torch.ones(1, device=coll_dev)
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
     # torch's CUDA generator creates its graph-safe state at the first capture in the process; done under inference_mode (the
     # rollout graphs below) those tensors could not be touched by the later training leg.  Prime them in normal mode, keep alive.
     rng_prime = torch.cuda.CUDAGraph()
@@ -91,8 +160,7 @@ def main():
     policy = ActorCritic(env.num_obs, env.num_obs, env.num_actions, **pol).to(dev)
     with contextlib.redirect_stdout(io.StringIO()):
         obs, _ = env.reset()
-    use_torch = a.torch_policy or a.policy == "torch"      # "auto" = the MFMA actor (all compiled shapes beat torch/hipBLASLt since the weight prefetch)
-    a.torch_policy = use_torch
+    use_torch = a.torch_policy or a.policy == "torch"
     if use_torch:
         policy_act = policy.act
     else:
@@ -116,7 +184,9 @@ def main():
                 if a.no_graph:
                     one_step()
                 fused_step = True
-            except RuntimeError:
+            except RuntimeError as exc:
+                if "fused policy step" not in str(exc):    # only "no fused kernel for this sim / actor pair" is a fall-back case
+                    raise
                 fused_step = False
         if fused_step:
             pass
@@ -127,72 +197,114 @@ def main():
             one_step = env.make_graphed_step(policy_act, steps_per_replay=G)      # policy forward + sampling + lg_step in ONE HIP graph
         for _ in range(a.warmup // G):
             one_step()
-        sync()
-        t0 = time.perf_counter()
-        for i in range(a.steps // G):                      # exactly a.steps policy steps: G per graph replay
-            one_step()
-        sync()
-        elapsed = time.perf_counter() - t0
-        # roofline: duration of the step kernel from HIP events (recorded on the launch stream) around replays of a HIP graph
-        # that holds ONLY that kernel, G launches back to back, directly after the timed region.  (Events around eager
-        # launches measure the host's enqueue latency instead: the kernel is shorter than one Python call.)
+
+        def timed_region():
+            """EXACTLY a.steps policy steps between barrier + synchronize; HIP events on the launch stream bracket the same replays."""
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            sync()
+            t0 = time.perf_counter()
+            e0.record()
+            for _ in range(a.steps // G):                  # G policy steps per graph replay
+                one_step()
+            e1.record()
+            sync()
+            return time.perf_counter() - t0, e0.elapsed_time(e1) * 1e-3
+
+        walls, evs = [], []
+        w, e = timed_region()
+        walls.append(w); evs.append(e)
+        # short run (the driver's --steps 20): repeat the region, report the median.  Rank 0 decides (regions contain barriers).
+        repeats = 1 if w * 1e3 >= a.min_timed_ms else int(min(400, max(9, round(0.5 / max(w, 1e-6)))))
+        if world > 1:
+            flag = torch.tensor([repeats], device=coll_dev)
+            dist.broadcast(flag, src=0)
+            repeats = int(flag.item())
+        for _ in range(repeats - 1):
+            w, e = timed_region()
+            walls.append(w); evs.append(e)
+
+        # step kernel alone, for tasks whose timed graph also holds the actor kernel: HIP events around replays of a graph that holds
+        # ONLY k_step, KG launches back to back, directly after the timed region
         if fused_step and not a.no_graph:
-            kernel_replay, KG = one_step, G                      # the timed graph already is G x k_step<..., POL>
+            kern_ms_each = [1e3 * e / a.steps for e in evs]     # the timed graph IS G x k_step<..., POL>: same replays, same region
+            kern_method = (f"HIP events on the launch stream around the {a.steps // G} graph replays of the timed region itself "
+                           f"(median of {repeats} regions; includes the ~1 us gaps between launches)")
         else:
             KG = 20
             fixed_actions = (policy_act(env.obs_buf) if not fused_step else fused.act(env.obs_buf)).clone()
-            kernel_replay = env.make_graphed_step(lambda _obs: fixed_actions, steps_per_replay=KG)   # G x lg_step, nothing else
-        n_rep = max(1, min(a.event_steps, a.steps) // KG)
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_rep)]
-        kernel_replay()
-        for s_, e_ in ev:
-            s_.record()
+            kernel_replay = env.make_graphed_step(lambda _obs: fixed_actions, steps_per_replay=KG)   # KG x lg_step, nothing else
+            n_rep = max(3, a.event_steps // KG)
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_rep)]
             kernel_replay()
-            e_.record()
-        torch.cuda.synchronize()
+            for s_, e_ in ev:
+                s_.record()
+                kernel_replay()
+                e_.record()
+            torch.cuda.synchronize()
+            kern_ms_each = [s_.elapsed_time(e_) / KG for s_, e_ in ev]
+            kern_method = f"HIP events around {n_rep} replays of a HIP graph of {KG} back-to-back launches of the step kernel alone, right after the timed region (median per-launch time)"
     finite = bool(torch.isfinite(env.obs_buf).all()) and bool(torch.isfinite(env.root_states).all())
-    kern_ms = sum(s_.elapsed_time(e_) for s_, e_ in ev) / (n_rep * KG)
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if (world == 1 or dist.get_backend() == "nccl") else "cpu")
+    kern_ms = statistics.median(kern_ms_each)
+    t = torch.tensor(walls, dtype=torch.float64, device=coll_dev)
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)           # per region: the slowest rank
+    elapsed = float(t.median().item()) if repeats > 1 else float(t[0].item())
 
-    out = None
+    training = None
+    iters = a.training_iters if a.training_iters >= 0 else (100 if a.task == "anymal_c_flat" else 20)
+    if iters > 0:
+        try:                                     # extra information, never allowed to take the headline line down
+            training = training_leg(a, iters, rank, local_rank, world, coll_dev, ranks_seen, backend)
+        except Exception as exc:
+            if world > 1:
+                raise                            # a rank that skips the leg would leave the others inside a collective
+            training = {"error": f"{type(exc).__name__}: {exc}"}
+
     if rank == 0:
+        from tools.flop_count import flops_per_env_step
         total_envs = a.num_envs * world
         value = total_envs * a.steps / elapsed
         bpe = BYTES_PER_ENV_STEP.get(a.task, 4022)
-        traffic = None                      # PMC bytes per k_step launch from the committed rocprofv3 passes (same workload only)
+        traffic, mfma_busy, pm_src = None, None, None   # PMC figures per k_step launch from the committed rocprofv3 passes (same workload only)
         try:
-            pm = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_summary.json")))
+            pm = json.load(open(PMC_SUMMARY))
             if a.task == "anymal_c_flat" and a.num_envs == 4096:
                 traffic = pm["k_step_traffic_bytes"]["fetch_doubled_sum"]
+                mfma_busy = 100.0 * pm["k_step_issue"]["mfma_busy_frac_of_busy_cycles"]
+                pm_src = os.path.relpath(PMC_SUMMARY, REPO) + " (rocprofv3 --pmc passes: FETCH_SIZE / WRITE_SIZE KiB, 2*FETCH+WRITE; SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES)"
         except Exception:
             pass
         achieved = bpe * a.num_envs / (kern_ms * 1e-3) / 1e9
+        fl = flops_per_env_step(a.task, int(env.cfg.control.decimation))
+        step_flops = fl["total"] - (0 if fused_step else fl["actor_mlp"])          # what the timed kernel computes
+        tflops = step_flops * a.num_envs / (kern_ms * 1e-3) / 1e12
+        kname = {"anymal_c_flat": "k_step<AnymalTraits,NET,plane" + (",POL> (actor + step)" if fused_step else ">"),
+                 "cassie": "k_step<CassieTraits,PD,HF>"}.get(a.task, "k_step<AnymalTraits," + ("NET" if getattr(env.cfg.control, "use_actuator_network", False) else "PD") + ",HF>")
         out = {
             "metric": "env-steps/sec (whole node), ANYmal-C flat 4096 envs/GPU" if a.task == "anymal_c_flat" else f"env-steps/sec (whole node), {a.task}",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{a.task}, {a.num_envs} envs/GPU, plane, actuator-net torques, random-init policy "
-                                   f"{[env.num_obs] + list(pol['actor_hidden_dims']) + [env.num_actions]} rollout (act = mu + sigma*eps), "
-                                   "fixed command (0.5,0,0), obs noise + friction/mass randomisation + pushes on",
+            "config": {"workload": workload_text(a.task, env, pol, a.num_envs),
                        "envs_per_gpu": a.num_envs, "decimation": int(env.cfg.control.decimation), "sim_dt": float(env.sim_params.dt),
                        "parallelism": f"env-sharded x{world}", "state_finite": finite,
                        "launch": ("eager" if a.no_graph else f"HIP graph of {G} policy steps per replay") + (": ONE kernel, actor fused into the step (lg_step_policy)" if fused_step else " (policy + lg_step)"),
-                       "policy": "torch ops (hipBLASLt)" if a.torch_policy else ("MFMA actor inside k_step (v_mfma_f32_16x16x4_f32, 4 waves)" if fused_step else "fused MFMA actor kernel (lg_policy_act, v_mfma_f32_16x16x4_f32)")},
+                       "policy": "torch ops (hipBLASLt)" if use_torch else ("MFMA actor inside k_step (v_mfma_f32_16x16x4_f32, 4 waves)" if fused_step else "fused MFMA actor kernel (lg_policy_act, v_mfma_f32_16x16x4_f32)")},
+            "repeats": repeats,
+            "timing": f"median of {repeats} timed regions of exactly {a.steps} steps each (a region shorter than {a.min_timed_ms:g} ms is repeated)" if repeats > 1 else f"one timed region of {a.steps} steps",
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": "profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, 2*FETCH+WRITE KiB)" if traffic else None, "kernel": ("k_step<AnymalTraits,NET,plane,POL> (actor + step)" if fused_step else "k_step<AnymalTraits,NET,plane>") if a.task != "cassie" else "k_step<CassieTraits>",
-                         "kernel_ms": kern_ms, "kernel_ms_method": f"HIP events around {n_rep} replays of a HIP graph of {KG} back-to-back launches of the step kernel alone, right after the timed region (per-launch average, includes ~1 us launch gap)",
+                         "traffic": traffic, "traffic_source": pm_src, "kernel": kname,
+                         "kernel_ms": kern_ms, "kernel_ms_method": kern_method,
                          "algorithmic_bytes_per_env_step": bpe,
-                         "note": "issue/latency-bound, not HBM-bound: 4096 envs = 256 workgroups x (1 rigid-body + 3 helper waves), one wave per SIMD, ~20k serial instructions on the rigid-body wave at one per ~6.5 cycles; see DESIGN.md section 5"},
+                         "flops": {"per_env_step": step_flops, "breakdown": fl, "achieved_tflops": tflops, "peak_tflops": FP32_VECTOR_PEAK_TFLOPS,
+                                   "frac": tflops / FP32_VECTOR_PEAK_TFLOPS, "mfma_busy_pct": mfma_busy,
+                                   "note": "counted fp32 flops of the timed kernel (tools/flop_count.py: ABA + contacts, actuator LSTM, actor when fused) / fp32 vector peak"},
+                         "note": "issue/latency-bound, not HBM-bound: one 512-register rigid-body wave per SIMD runs a serial chain of ~20k instructions; state is L2/MALL-resident; see DESIGN.md section 5"},
         }
-        if world == 1 and a.training_iters > 0 and a.task == "anymal_c_flat":
-            try:                                 # extra information, never allowed to take the headline line down
-                out["ppo_training"] = training_leg(a)
-            except Exception as exc:
-                out["ppo_training"] = {"error": f"{type(exc).__name__}: {exc}"}
+        if world > 1:
+            out["rccl_ranks" if backend == "nccl" else f"{backend}_ranks"] = ranks_seen
+        if training is not None:
+            out["ppo_training"] = training
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a)
         print(json.dumps(out), flush=True)
@@ -201,31 +313,50 @@ def main():
         dist.destroy_process_group()
 
 
-def training_leg(a):
+def training_leg(a, iters, rank, local_rank, world, coll_dev, ranks_seen, backend):
     """Not the headline metric: env-steps/s of the whole PPO loop (24-step rollouts + 5 x 4 mini-batch updates per iteration,
-    reference anymal_c_flat train cfg) with the bundled runner -- rollout graph of lg_step_policy + lg_rollout_record, update =
-    lg_mlp_forward / lg_ppo_loss / lg_mlp_backward / lg_adam_step replayed as one HIP graph per mini-batch."""
+    reference train cfg) with the bundled runner -- rollout graph + lg_rollout_record, update on the MFMA learner kernels where
+    the networks have a compiled shape.  At world > 1 every iteration contains the RCCL all-gather of [returns || advantages]
+    and, per mini-batch, the gradient and mean-KL all-reduces (rl/ppo.py); time = max over ranks between barriers."""
+    import contextlib
+    import io
     import torch
+    import torch.distributed as dist
     from legged_games_gym_amd.envs import task_registry
     from legged_games_gym_amd.utils import get_args
-    import contextlib, io
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
     with contextlib.redirect_stdout(io.StringIO()):              # rank 0 prints ONE line: everything here stays silent
-        args = get_args(["--task", a.task, "--headless", "--sim_device", "cuda:0", "--rl_device", "cuda:0", "--num_envs", str(a.num_envs)])
-        env, _ = task_registry.make_env(a.task, args)
+        args = get_args(["--task", a.task, "--headless", "--sim_device", f"cuda:{local_rank}", "--rl_device", f"cuda:{local_rank}", "--num_envs", str(a.num_envs)])
+        env_cfg, train_cfg = task_registry.get_cfgs(a.task)
+        env_cfg.seed = train_cfg.seed + rank
+        env, _ = task_registry.make_env(a.task, args, env_cfg=env_cfg)
         runner, train_cfg = task_registry.make_alg_runner(env, a.task, args, log_root=None)
         runner.learn(num_learning_iterations=6, init_at_random_ep_len=True)      # eager warm-up update, graph captures
-        torch.cuda.synchronize()
+        sync()
         t0 = time.perf_counter()
-        runner.learn(num_learning_iterations=a.training_iters)
-        torch.cuda.synchronize()
+        runner.learn(num_learning_iterations=iters)
+        sync()
         dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
     T = int(train_cfg.runner.num_steps_per_env)
     alg = runner.alg
-    return {"value": a.num_envs * T * a.training_iters / dt, "unit": "env-steps/s (rollout + PPO update)", "iterations": a.training_iters,
-            "ms_per_iteration": 1e3 * dt / a.training_iters, "steps_per_env": T, "epochs_x_minibatches": [alg.num_learning_epochs, alg.num_mini_batches],
-            "update_path": "MFMA learner kernels" if getattr(alg, "_mlp", None) is not None else "torch autograd",
-            "final_learning_rate": float(alg.learning_rate),
-            "note": "includes re-capturing the rollout graph at the start of the timed learn() call"}
+    out = {"value": world * a.num_envs * T * iters / dt, "unit": "env-steps/s (rollout + PPO update, whole job)", "iterations": iters,
+           "ms_per_iteration": 1e3 * dt / iters, "steps_per_env": T, "epochs_x_minibatches": [alg.num_learning_epochs, alg.num_mini_batches],
+           "update_path": getattr(alg, "update_path_name", lambda: "MFMA learner kernels" if getattr(alg, "_mlp", None) is not None else "torch autograd")(),
+           "final_learning_rate": float(alg.learning_rate),
+           "note": "includes re-capturing the rollout graph at the start of the timed learn() call"}
+    if world > 1:
+        out["collectives_per_iteration"] = {"all_gather_returns_advantages": 1, "gradient_all_reduce": alg.num_learning_epochs * alg.num_mini_batches,
+                                            "kl_all_reduce": alg.num_learning_epochs * alg.num_mini_batches if alg.schedule == "adaptive" else 0,
+                                            "backend": "nccl (RCCL)" if backend == "nccl" else backend, "ranks": ranks_seen}
+    return out
 
 
 def _usable_cores():
@@ -265,7 +396,7 @@ def cpu_baseline(a):
         o.step(acts[i % 8], 3 + i)
     dt = time.perf_counter() - t0
     return {"value": N * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{N} envs x {steps} policy steps of the same workload (env step only, N(0,1) actions), "
+            "sample": f"{N} envs x {steps} policy steps of the same workload on the plane (env step only, N(0,1) actions), "
                       f"oracle/lg_oracle.c with OpenMP over envs; PhysX CPU path of the reference is not runnable here"}
 
 

@@ -1,0 +1,41 @@
+"""-m gpu: bench.py's launch paths.  `--gpus 2` without a launcher must start two ranks itself, see both through a real
+collective and report the whole-job line with the PPO leg that carries the update collectives (rehearsed with gloo on the
+one GPU of the test box: LG_BENCH_BACKEND=gloo; on an N-GPU node the same code runs with backend nccl = RCCL)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.realpath(__file__)))
+
+
+def _run(extra, env=None):
+    e = dict(os.environ, **(env or {}))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        e.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + extra, capture_output=True, text=True, timeout=420, env=e, cwd=REPO)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]           # ONE JSON line, from rank 0 only
+    return json.loads(lines[0])
+
+
+def test_short_run_is_repeated_and_kernel_time_is_consistent():
+    out = _run(["--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--training-iters", "0"])
+    assert out["n_gpus"] == 1 and out["steps"] == 20 and out["repeats"] >= 9
+    assert out["roofline"]["kernel_ms"] <= out["ms_per_step"] * 1.0001          # events bracket the same replays inside the host bracket
+    assert 0.0 < out["roofline"]["frac"] < 1.0 and 0.0 < out["roofline"]["flops"]["frac"] < 1.0
+    assert out["config"]["state_finite"] and "self-collision" in out["config"]["workload"]
+
+
+def test_gpus_2_spawns_two_ranks_and_reports_the_collectives():
+    out = _run(["--gpus", "2", "--steps", "40", "--warmup", "20", "--num-envs", "1024", "--no-cpu-baseline", "--training-iters", "3"],
+               env={"LG_BENCH_BACKEND": "gloo"})
+    assert out["n_gpus"] == 2 and out["gloo_ranks"] == 2 and out["config"]["parallelism"] == "env-sharded x2"
+    tr = out["ppo_training"]
+    assert "error" not in tr and tr["collectives_per_iteration"]["ranks"] == 2
+    assert tr["collectives_per_iteration"]["all_gather_returns_advantages"] == 1 and tr["collectives_per_iteration"]["gradient_all_reduce"] == 20
+    assert tr["value"] > 0 and out["value"] > 0
