@@ -56,12 +56,16 @@ class LeggedRobot(BaseTask):
         self._sim.set_obs_output(self.obs_buf)
         # while a caller captures a multi-step HIP graph (rl/runner.py) the counter must come from the device
         self._sim.step(actions, -1 if self._capturing else self.common_step_counter)
+        if self.cfg.commands.curriculum:
+            self._command_curriculum_tick()
         return self.obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf, self.extras
 
     def step_policy(self, fused_actor, deterministic=False):
         """Rollout step with the actor fused in: ``actions = fused_actor(obs_buf)`` and ``step(actions)`` as ONE launch
         (``lg_step_policy``).  Returns ``(actions, mean), (obs, privileged_obs, rew, dones, extras)``.  Only for the
         compiled fused shape (flat ANYmal actor on the plane); raises RuntimeError otherwise -- use ``step``."""
+        if self.cfg.commands.curriculum and self._capturing:
+            raise NotImplementedError("commands.curriculum needs eager steps (host-side rule between steps)")
         self.common_step_counter += 1
         prev_obs = self.obs_buf
         self._obs_flip ^= 1
@@ -75,13 +79,38 @@ class LeggedRobot(BaseTask):
             self.obs_buf = prev_obs
             self._sim.set_obs_output(self.obs_buf)
             raise
+        if self.cfg.commands.curriculum:
+            self._command_curriculum_tick()
         return am, (self.obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf, self.extras)
 
     def post_physics_step(self):
         raise RuntimeError("post_physics_step is fused into lg_step; call step()")
 
+    def _command_curriculum_tick(self):
+        """reset_idx :159-168 for resets that happen INSIDE the fused step: every ``max_episode_length`` policy steps, if envs
+        were reset by this step, apply ``update_command_curriculum`` to them (host rule, one device read per 1000 steps).
+        The kernel has already zeroed the episode sums of those envs; their mean is what it published in ``episode_means``
+        (= mean over the reset envs / max_episode_length_s, :179-183)."""
+        if self._capturing:
+            raise NotImplementedError("commands.curriculum is a host-side rule evaluated between steps: it cannot be captured into a "
+                                      "multi-step HIP graph (use eager steps; the bundled runner falls back by itself)")
+        if self.common_step_counter % self.max_episode_length != 0 or "tracking_lin_vel" not in self.episode_sums:
+            return
+        if not bool(self.reset_buf.any()):
+            return
+        i = self.reward_names_all.index("tracking_lin_vel")
+        mean_sum = float(self._episode_means[i]) * self.max_episode_length_s
+        if mean_sum / self.max_episode_length > 0.8 * self.reward_scales["tracking_lin_vel"]:
+            r = self.command_ranges["lin_vel_x"]
+            r[0] = np.clip(r[0] - 0.5, -self.cfg.commands.max_curriculum, 0.0)
+            r[1] = np.clip(r[1] + 0.5, 0.0, self.cfg.commands.max_curriculum)
+            self.set_command_ranges()
+        self.extras["episode"]["max_command_x"] = self.command_ranges["lin_vel_x"][1]
+
     def begin_graph_capture(self):
         """Prepare for capturing several step() calls into one HIP graph: the step counter moves to the device."""
+        if self.cfg.commands.curriculum:
+            raise NotImplementedError("commands.curriculum needs eager steps (host-side rule between steps)")
         self._sim.buf["step_counter"].fill_(self.common_step_counter)
         self._capturing = True
 
@@ -94,6 +123,8 @@ class LeggedRobot(BaseTask):
         zero-argument callable that replays it (launch-bound inner loop -> one hipGraphLaunch).
         The step counter lives on the device while replaying (``lg_step(..., -1)``), the host copy is
         advanced alongside.  ``policy_act`` must be capturable (no host syncs) and read ``self.obs_buf``."""
+        if self.cfg.commands.curriculum:
+            raise NotImplementedError("commands.curriculum needs eager steps (host-side rule between steps)")
         sim = self._sim
         sim.set_obs_output(self.obs_buf)                  # single fixed buffer while replaying (the policy reads it inside the graph)
         sim.buf["step_counter"].fill_(self.common_step_counter)
@@ -119,6 +150,8 @@ class LeggedRobot(BaseTask):
     def make_graphed_policy_step(self, fused_actor, warmup=3, steps_per_replay=1):
         """Like ``make_graphed_step`` with the actor fused into the step kernel: the graph is ONE ``lg_step_policy`` launch
         (obs_buf -> actions -> next obs_buf, in place).  Raises RuntimeError when the sim / actor pair has no fused kernel."""
+        if self.cfg.commands.curriculum:
+            raise NotImplementedError("commands.curriculum needs eager steps (host-side rule between steps)")
         sim = self._sim
         sim.set_obs_output(self.obs_buf)
         sim.buf["step_counter"].fill_(self.common_step_counter)

@@ -60,10 +60,12 @@ class OnPolicyRunner:
                 (actions, mean), out = env.step_policy(fused)
                 self._fused_step = True
                 return actions, mean, out
-            except RuntimeError:
-                if self._fused_step:
+            except RuntimeError as exc:
+                # only "no fused kernel for this sim / actor pair" (lg_step_policy rc -4) selects the two-kernel path;
+                # a real HIP failure must surface
+                if self._fused_step or "fused policy step" not in str(exc):
                     raise
-                self._fused_step = False                      # no fused kernel for this sim / actor pair
+                self._fused_step = False
         actions, mean = fused.act_with_mean(obs)
         return actions, mean, env.step(actions)
 
@@ -144,6 +146,8 @@ class OnPolicyRunner:
               and self.cfg.get("graphed_rollout", True))
         if not ok:
             return None
+        flip0, counter0 = getattr(env, "_obs_flip", 0), env.common_step_counter
+        captured = False
         try:
             N, dev = env.num_envs, self.device
             sums = torch.zeros(3, device=dev)             # {sum of finished-episode returns, of their lengths, their count}
@@ -157,10 +161,12 @@ class OnPolicyRunner:
                 torch.cuda.synchronize()
                 flip0, counter0 = env._obs_flip, env.common_step_counter
                 env.begin_graph_capture()
+                captured = True
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
                     obs, cobs = self._rollout_steps(stats)
                 env.end_graph_capture(self.num_steps_per_env)
+                captured = False
                 assert env._obs_flip == flip0 and env.common_step_counter == counter0
             self.alg.storage.clear()
             return graph, stats, obs, cobs
@@ -168,6 +174,13 @@ class OnPolicyRunner:
             print(f"[runner] graphed rollout unavailable ({type(exc).__name__}: {exc}); using eager steps")
             if hasattr(env, "_capturing"):
                 env._capturing = False
+            if captured:
+                # steps issued during a capture that failed part-way were counted but never executed: put the observation
+                # ping-pong and the step counter (push / resample / RNG phase) back where they were
+                env._obs_flip = flip0
+                env.obs_buf = env._obs_pair[flip0]
+                env._sim.set_obs_output(env.obs_buf)
+                env.common_step_counter = counter0
             self.alg.storage.clear()
             return None
 

@@ -182,11 +182,20 @@ def buffer_spec(p, model) -> Dict[str, Tuple[Tuple[int, ...], str]]:
 
 def load_actuator_weights(path: str = None) -> np.ndarray:
     """The 972-float blob extracted from the reference's anydrive_v3_lstm.pt
-    (tools/compile_models.py; raw storages, nothing executed)."""
+    (tools/compile_models.py; raw storages, nothing executed).
+
+    ``path`` may be a ``.f32`` blob, ``None``, or the registered config's ``.../anydrive_v3_lstm.pt`` (for which the bundled
+    extraction is used).  Any OTHER TorchScript file is refused: silently running the bundled net's dynamics in its place
+    would be wrong."""
     import os
-    if path is None or not path.endswith(".f32"):
-        here = os.path.dirname(os.path.dirname(os.path.realpath(__file__)))
-        path = os.path.join(here, "resources", "actuator_nets", "anydrive_v3_lstm.f32")
+    here = os.path.dirname(os.path.dirname(os.path.realpath(__file__)))
+    bundled = os.path.join(here, "resources", "actuator_nets", "anydrive_v3_lstm.f32")
+    if path is None or os.path.basename(path) == "anydrive_v3_lstm.pt":
+        path = bundled
+    elif not path.endswith(".f32"):
+        raise ValueError(f"control.actuator_net_file = {path!r}: only 972-float .f32 blobs are loaded (TorchScript archives are never "
+                         "executed here); convert the file with tools/compile_models.py (static, no-code extraction) and point the "
+                         "config at the resulting .f32")
     w = np.fromfile(path, dtype="<f4")
     if w.size != capi.LG_ACTUATOR_FLOATS:
         raise ValueError(f"{path}: expected {capi.LG_ACTUATOR_FLOATS} floats, found {w.size}")

@@ -31,6 +31,7 @@ class TaskRegistry:
         self.task_classes = {}
         self.env_cfgs = {}
         self.train_cfgs = {}
+        self.experimental = {}        # task name -> caveat printed by make_env (not part of the reference's registry)
 
     def register(self, name, task_class, env_cfg, train_cfg):
         self.task_classes[name] = task_class
@@ -53,6 +54,9 @@ class TaskRegistry:
             task_class = self.get_task_class(name)
         else:
             raise ValueError(f"Task with name: {name} was not registered")
+        if name in self.experimental:
+            import warnings
+            warnings.warn(f"task '{name}' is EXPERIMENTAL in legged_games_gym_amd: {self.experimental[name]}", stacklevel=2)
         if env_cfg is None:
             env_cfg, _ = self.get_cfgs(name)
         env_cfg, _ = update_cfg_from_args(env_cfg, None, args)
@@ -74,20 +78,45 @@ class TaskRegistry:
         _, train_cfg = update_cfg_from_args(None, train_cfg, args)
 
         stamp = datetime.now().strftime("%b%d_%H-%M-%S") + "_" + train_cfg.runner.run_name
+        default_root = os.path.join(LEGGED_GYM_ROOT_DIR, "logs", train_cfg.runner.experiment_name)
         if log_root == "default":
-            log_root = os.path.join(LEGGED_GYM_ROOT_DIR, "logs", train_cfg.runner.experiment_name)
+            log_root = default_root
             log_dir = os.path.join(log_root, stamp)
         elif log_root is None:
-            log_dir = None
+            log_dir = None                   # this process writes no logs (ranks > 0 of a multi-GPU job) ...
+            log_root = default_root          # ... but a resume still finds the checkpoint where rank 0 saved it
         else:
             log_dir = os.path.join(log_root, stamp)
 
         runner = _runner_class()(env, class_to_dict(train_cfg), log_dir, device=args.rl_device)
         if train_cfg.runner.resume:
-            resume_path = get_load_path(log_root, load_run=train_cfg.runner.load_run, checkpoint=train_cfg.runner.checkpoint)
+            resume_path = self._resume_path(log_root, train_cfg)
             print(f"Loading model from: {resume_path}")
-            runner.load(resume_path)
+            runner.load(resume_path)             # every rank loads the same file: replicas (weights + Adam state) start identical
         return runner, train_cfg
+
+
+    @staticmethod
+    def _resume_path(log_root, train_cfg):
+        """Checkpoint to resume from.  In a multi-process job rank 0 resolves it (before its own new run directory exists
+        on disk) and the others receive the string: a rank listing the log root later could pick rank 0's fresh, empty run."""
+        try:
+            import torch.distributed as dist
+            multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        except ImportError:
+            multi = False
+        if not multi:
+            return get_load_path(log_root, load_run=train_cfg.runner.load_run, checkpoint=train_cfg.runner.checkpoint)
+        box = [None]
+        if dist.get_rank() == 0:
+            try:
+                box[0] = get_load_path(log_root, load_run=train_cfg.runner.load_run, checkpoint=train_cfg.runner.checkpoint)
+            except ValueError as exc:
+                box[0] = exc
+        dist.broadcast_object_list(box, src=0)
+        if isinstance(box[0], Exception):
+            raise box[0]
+        return box[0]
 
 
 task_registry = TaskRegistry()

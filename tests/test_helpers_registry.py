@@ -120,3 +120,20 @@ def test_runner_scalar_log_uses_rsl_rl_tag_names(tmp_path):
         assert tag in cols
     assert len(lines) == 3 and lines[2].split(",")[cols.index("Train/mean_reward")] == "1.5"
     assert lines[2].split(",")[cols.index("Episode/rew_torques")] == "-0.25"
+
+
+def test_a1_is_flagged_experimental_and_custom_actuator_files_are_refused(tmp_path):
+    """`make_env('a1')` must not hand out a task known not to train without saying so; a user's own TorchScript
+    actuator file must not be silently replaced by the bundled net."""
+    import numpy as np
+    import pytest
+    from legged_games_gym_amd.envs import task_registry
+    from legged_games_gym_amd.utils import packing
+    assert "a1" in task_registry.experimental and "anymal_c_flat" not in task_registry.experimental
+    assert packing.load_actuator_weights("/somewhere/resources/actuator_nets/anydrive_v3_lstm.pt").size == 972
+    assert packing.load_actuator_weights(None).size == 972
+    with pytest.raises(ValueError, match="compile_models"):
+        packing.load_actuator_weights(str(tmp_path / "my_own_net.pt"))
+    blob = tmp_path / "net.f32"
+    np.arange(972, dtype="<f4").tofile(blob)
+    assert packing.load_actuator_weights(str(blob))[5] == 5.0
