@@ -105,7 +105,7 @@ def test_post_physics_block_parity(task):
             assert maxdiff(o, d, k) <= tol, (k, step, maxdiff(o, d, k))
         if "sea_hidden_state" in o.buf:
             assert maxdiff(o, d, "sea_hidden_state") == 0.0
-    assert o.buf["reset_buf"].sum() > 5
+    assert o.buf["reset_buf"].sum() >= 3            # (the step-750 resets were re-initialised: fewer remain at 751)
 
 
 @pytest.mark.parametrize("task", ["anymal_c_flat", "cassie", "anymal_c_rough", "a1"])
