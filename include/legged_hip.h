@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LG_ABI_VERSION        19
+#define LG_ABI_VERSION        20
 
 #define LG_MAX_LIMBS          4
 #define LG_MAX_CHAIN          6
@@ -109,7 +109,8 @@ typedef struct lg_params {
     /* terrain: legged_robot.py:609-637, 831-869; terrain.py */
     int32_t terrain_type, hf_rows, hf_cols, custom_origins;
     float   hf_horizontal_scale, hf_vertical_scale, hf_border, _padf3;
-    int32_t terrain_curriculum, terrain_num_rows, terrain_num_cols, _padi0;
+    int32_t terrain_curriculum, terrain_num_rows, terrain_num_cols;
+    int32_t self_collision;            /* 1: links of one robot collide with each other (asset.self_collisions == 0, legged_robot.py:683; anymal_c_flat_config.py:42) */
     float   terrain_env_length, max_episode_length_s;
     /* reset: legged_robot.py:397-436 */
     float   base_init_state[13], _padf4;

@@ -32,14 +32,29 @@ struct AnymalTraits {          // quadruped (ANYmal-C/B, A1): base + 4 legs x 3 
     static constexpr int pt_joint(int i) { return i < 2 ? 1 : 2; }
     static constexpr int pt_rep(int i) { return i < 2 ? 1 : (i < 4 ? 2 : 3); }
     static constexpr int FOOT_REP = 3;
+    // self-collision shapes: capsule c = segment between points cap_p0(c), cap_p1(c) (a sphere when equal): KFE-drive capsule on the
+    // thigh, shank capsule, foot sphere; bounding groups (culling): g0 = drive (joint 1), g1 = shank + foot (joint 2)
+    static constexpr int NCAP = 3, NGRP = 2;
+    static constexpr int cap_p0(int c) { return 2 * c; }
+    static constexpr int cap_p1(int c) { return c < 2 ? 2 * c + 1 : 4; }
+    static constexpr int cap_grp(int c) { return c == 0 ? 0 : 1; }
+    static constexpr int grp_c0(int g) { return g == 0 ? 0 : 2; }       // group centre = midpoint of these two points
+    static constexpr int grp_c1(int g) { return g == 0 ? 1 : 4; }
 };
 struct CassieTraits {          // pelvis + 2 legs x 6 joints; points: toe capsule
     static constexpr int K = 2, L = 6, NREP = 6, NPT = 2;
     static constexpr int pt_joint(int) { return 5; }
     static constexpr int pt_rep(int) { return 5; }
     static constexpr int FOOT_REP = 5;
+    static constexpr int NCAP = 1, NGRP = 1;                            // toe capsule
+    static constexpr int cap_p0(int) { return 0; }
+    static constexpr int cap_p1(int) { return 1; }
+    static constexpr int cap_grp(int) { return 0; }
+    static constexpr int grp_c0(int) { return 0; }
+    static constexpr int grp_c1(int) { return 1; }
 };
-template <class T> struct Tab { static constexpr int STRIDE = T::L * LG_JS + 4 * T::NPT + 1; };
+template <class T> struct Tab { static constexpr int GRP = T::L * LG_JS + 4 * T::NPT;                 // bounding radius of each point group
+                          static constexpr int STRIDE = GRP + T::NGRP + 1; };
 // per-joint offsets inside the limb table
 enum { J_POS = 0, J_ROT = 3, J_AXIS = 12, J_MASS = 15, J_COM = 16, J_INERTIA = 19, J_LO = 25, J_HI = 26, J_VLIM = 27,
        J_ARM = 28, J_DAMP = 29, J_KP = 30, J_KD = 31, J_Q0 = 32, J_TLIM = 33, J_SLO = 34, J_SHI = 35, J_DVL = 36 };
@@ -247,16 +262,167 @@ LG_DEV void bt_load(const float4 (*src)[LG_BLOCK], int lane, AI &I, S6 &p) {
     I.M[1] = e.x; I.M[2] = e.y; I.M[3] = e.z; I.M[4] = e.w; I.M[5] = f.x; p.w = v3(f.y, f.z, f.w); p.v = v3(g.x, g.y, g.z);
 }
 
+// ------------------------------------------------------------------ self-collision (asset.self_collisions = 0; DESIGN.md "Self-collision")
+// Twin of oracle/lg_oracle.c "self-collision": limb capsules against the base capsules and against the capsules of the other
+// limbs; frictionless implicit spring-dampers, block-Jacobi between the two bodies.  Lane (env, limb k) owns limb k's side of
+// every pair and the base reaction of its deepest base contact.  Collision spheres travel between the K lanes of an env
+// through LDS (same wave: no barrier); group bounding spheres cull, and every narrow-phase pair test is skipped wave-uniformly
+// unless some lane of the wave flagged that group pair.
+template <class T> struct SelfLds {
+    float4 pos[T::NPT][LG_BLOCK];        // sphere centres relative to the base origin (world axes); w = radius
+    float4 vel[T::NPT][LG_BLOCK];        // their velocities
+    float4 grp[T::NGRP][LG_BLOCK];       // bounding sphere of each point group: centre, radius
+    float4 base[2][LG_BLOCK];            // reaction of the lane's deepest base contact: (c x n, depth), (n, f0); depth < -1e29: none
+    float4 frc[T::NCAP + 1][LG_BLOCK];   // self-collision force on each capsule's report body, [NCAP]: this lane's share on the base
+};
+struct CapD { V3 a0, a1, v0, v1; float rad; };
+LG_DEV V3 xyz(float4 a) { return v3(a.x, a.y, a.z); }
+LG_DEV void seg_seg_closest(V3 a0, V3 a1, V3 b0, V3 b1, float &s, float &t) {     // Ericson, RTCD 5.1.9
+    const float eps = 1e-12f;
+    V3 d1 = a1 - a0, d2 = b1 - b0, r = a0 - b0;
+    float a = dot(d1, d1), e = dot(d2, d2), f = dot(d2, r);
+    if (a <= eps && e <= eps) { s = 0.0f; t = 0.0f; }
+    else if (a <= eps) { s = 0.0f; t = fminf(fmaxf(f / e, 0.0f), 1.0f); }
+    else {
+        float c = dot(d1, r);
+        if (e <= eps) { t = 0.0f; s = fminf(fmaxf(-c / a, 0.0f), 1.0f); }
+        else {
+            float b = dot(d1, d2), denom = a * e - b * b;
+            s = (denom > eps) ? fminf(fmaxf((b * f - c * e) / denom, 0.0f), 1.0f) : 0.0f;
+            t = (b * s + f) / e;
+            if (t < 0.0f) { t = 0.0f; s = fminf(fmaxf(-c / a, 0.0f), 1.0f); }
+            else if (t > 1.0f) { t = 1.0f; s = fminf(fmaxf((b - c) / a, 0.0f), 1.0f); }
+        }
+    }
+}
+LG_DEV bool capsule_contact(const lg_params &P, const CapD &A, const CapD &B, float kn, V3 &n, float &depth, float &f0, V3 &pa, V3 &pb) {
+    float s, t;
+    seg_seg_closest(A.a0, A.a1, B.a0, B.a1, s, t);
+    V3 ca = A.a0 + (A.a1 - A.a0) * s, cb = B.a0 + (B.a1 - B.a0) * t, diff = ca - cb;
+    float dist = sqrtf(dot(diff, diff));
+    float d = A.rad + B.rad - dist;
+    if (!(d > -P.contact_margin)) return false;
+    n = diff * (1.0f / fmaxf(dist, 1e-9f));
+    V3 va = A.v0 + (A.v1 - A.v0) * s, vb = B.v0 + (B.v1 - B.v0) * t;
+    float f = P.contact_stiffness * d - kn * dot(n, va - vb);
+    if (!(f > 0.0f)) return false;
+    depth = d; f0 = f; pa = ca - n * A.rad; pb = cb + n * B.rad;
+    return true;
+}
+template <class T> LG_DEV CapD load_cap(const SelfLds<T> &sc, int lane, int p0, int p1) {
+    CapD c; float4 a = sc.pos[p0][lane], b = sc.pos[p1][lane];
+    c.a0 = xyz(a); c.a1 = xyz(b); c.rad = a.w; c.v0 = xyz(sc.vel[p0][lane]); c.v1 = xyz(sc.vel[p1][lane]);
+    return c;
+}
+// Returns (wave-uniform) whether any lane of the wave went through the narrow phase: only then do sc.base / sc.frc hold data.
+template <class T>
+LG_DEV bool self_collide(const KArgs &A, const float *tab, int ln, const float (&root)[13], const V3 (&db)[T::L], AI (&I0)[T::L], S6 (&p0)[T::L], SelfLds<T> &sc) {
+    constexpr int K = T::K, L = T::L, NCAP = T::NCAP, NGRP = T::NGRP;
+    static_assert(K * NGRP * NGRP <= 32, "candidate bit mask");
+    const lg_params &P = A.P;
+    const float dt = P.sim_dt, kn = P.contact_stiffness * dt + P.contact_damping, margin = P.contact_margin;
+    __builtin_amdgcn_wave_barrier();                                   // the kinematics loop's LDS writes precede these reads (one wave, in order)
+    V3 gc[NGRP]; float gr[NGRP];
+#pragma unroll
+    for (int g = 0; g < NGRP; g++) {
+        gc[g] = (xyz(sc.pos[T::grp_c0(g)][ln]) + xyz(sc.pos[T::grp_c1(g)][ln])) * 0.5f;
+        gr[g] = tab[Tab<T>::GRP + g];
+        sc.grp[g][ln] = make_float4(gc[g].x, gc[g].y, gc[g].z, gr[g]);
+    }
+    // base capsules (points come in equal-radius pairs; checked at lg_create), world axes about the base origin
+    const M3 R0 = quat_to_mat(root + 3);
+    const V3 w0 = v3(root[10], root[11], root[12]), v0 = v3(root[7], root[8], root[9]);
+    const int nbc = (A.base.num_pts + 1) >> 1;
+    CapD bc[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const int i0 = min(2 * c, LG_MAX_BASE_POINTS - 1), i1 = (2 * c + 1 < A.base.num_pts) ? 2 * c + 1 : i0;
+        bc[c].a0 = mul(R0, v3(A.base.pts[i0][0], A.base.pts[i0][1], A.base.pts[i0][2]));
+        bc[c].a1 = mul(R0, v3(A.base.pts[i1][0], A.base.pts[i1][1], A.base.pts[i1][2]));
+        bc[c].v0 = v0 + cross(w0, bc[c].a0); bc[c].v1 = v0 + cross(w0, bc[c].a1); bc[c].rad = A.base.pts[i0][3];
+    }
+    // ---- stage 1: which (partner, my group, their group) bounding spheres touch?  bit ((m * NGRP + ga) * NGRP + gb), m = 0: base
+    unsigned cand = 0;
+#pragma unroll
+    for (int ga = 0; ga < NGRP; ga++) {
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            V3 d = bc[c].a1 - bc[c].a0, rel = gc[ga] - bc[c].a0;
+            float dd = dot(d, d), t = dd > 0.0f ? fminf(fmaxf(dot(rel, d) / dd, 0.0f), 1.0f) : 0.0f;
+            V3 off = rel - d * t;
+            float lim = gr[ga] + bc[c].rad + margin;
+            if (c < nbc && dot(off, off) < lim * lim) cand |= 1u << (ga * NGRP);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int m = 1; m < K; m++) {
+#pragma unroll
+        for (int gb = 0; gb < NGRP; gb++) {
+            const float4 o = sc.grp[gb][ln ^ m];
+#pragma unroll
+            for (int ga = 0; ga < NGRP; ga++) {
+                V3 off = gc[ga] - xyz(o);
+                float lim = gr[ga] + o.w + margin;
+                if (dot(off, off) < lim * lim) cand |= 1u << ((m * NGRP + ga) * NGRP + gb);
+            }
+        }
+    }
+    if (__builtin_amdgcn_ballot_w64(cand != 0) == 0) return false;
+    // ---- stage 2 (rare): narrow phase, limb side folded into the body's rigid terms, deepest base contact kept for the passes
+#pragma unroll
+    for (int c = 0; c <= NCAP; c++) sc.frc[c][ln] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float best = -1e30f, best_f0 = 0.0f; V3 best_cxn = v3(0, 0, 0), best_n = v3(0, 0, 0);
+#pragma unroll 1
+    for (int m = 0; m < K; m++) {
+        const int lp = ln ^ m, nother = m == 0 ? nbc : NCAP;
+#pragma unroll 1
+        for (int i = 0; i < NCAP; i++) {
+#pragma unroll 1
+            for (int j = 0; j < nother; j++) {
+                const unsigned bit = 1u << ((m * NGRP + T::cap_grp(i)) * NGRP + (m == 0 ? 0 : T::cap_grp(j)));
+                if (__builtin_amdgcn_ballot_w64((cand & bit) != 0) == 0) continue;       // wave-uniform skip
+                const CapD Ac = load_cap<T>(sc, ln, T::cap_p0(i), T::cap_p1(i));
+                CapD Bc;
+                if (m == 0) Bc = j == 0 ? bc[0] : bc[1];
+                else Bc = load_cap<T>(sc, lp, T::cap_p0(j), T::cap_p1(j));
+                V3 n, pa, pb; float depth, f0;
+                if ((cand & bit) && capsule_contact(P, Ac, Bc, kn, n, depth, f0, pa, pb)) {
+                    const int jc = T::pt_joint(T::cap_p0(i));
+                    V3 rj = db[0];
+#pragma unroll
+                    for (int jj = 1; jj < L; jj++) if (jj <= jc) rj = rj + db[jj];
+                    const V3 r = pa - rj, f = n * f0, rxn = cross(r, n);
+#pragma unroll
+                    for (int jj = 0; jj < L; jj++) if (jj == jc) {
+                        ai_add_rank1(I0[jj], dt * kn, rxn, n);
+                        p0[jj].w = p0[jj].w - cross(r, f); p0[jj].v = p0[jj].v - f;
+                    }
+                    float4 acc = sc.frc[i][ln];
+                    sc.frc[i][ln] = make_float4(acc.x + f.x, acc.y + f.y, acc.z + f.z, 0.0f);
+                    if (m == 0 && depth > best) { best = depth; best_f0 = f0; best_n = n; best_cxn = cross(pb, n); }
+                }
+            }
+        }
+    }
+    sc.base[0][ln] = make_float4(best_cxn.x, best_cxn.y, best_cxn.z, best);
+    sc.base[1][ln] = make_float4(best_n.x, best_n.y, best_n.z, best_f0);
+    if (best > -1e29f) sc.frc[NCAP][ln] = make_float4(-best_n.x * best_f0, -best_n.y * best_f0, -best_n.z * best_f0, 0.0f);
+    return true;
+}
+
 // `torques_ready` runs between the kinematics half (needs no torques) and the articulated-body passes: the fused step
 // uses it to join the actuator waves, which compute this sub-step's torques meanwhile (k_step).
 struct NoWait { LG_DEV void operator()() const {} };
 // OFFLOAD: the limb bodies' (I0, p0) are computed by the helper waves meanwhile and read from `bt` after `torques_ready`.
-template <class T, bool HF, class Ready = NoWait, bool OFFLOAD = false>
+// SC: self-collision (needs `sc`); `last`: the exported net contact forces (Frep / Fbase after this call) include the
+// self-collision forces -- the policy step's last sub-step, or the sub-step entry point.
+template <class T, bool HF, class Ready = NoWait, bool OFFLOAD = false, bool SC = false>
 LG_DEV void physics_substep(const KArgs &A, const float *tab, int lane_k, float (&root)[13], float (&q)[T::L], float (&qd)[T::L],
                             const float (&tau)[T::L], float base_mass, float mu,
                             float (&Frep)[T::NREP][3], float (&Fbase)[3], Ready torques_ready = Ready(),
                             const float4 (*bt)[LG_BT_QUADS][LG_BLOCK] = nullptr, float4 (*fkout)[4][LG_BLOCK] = nullptr,
-                            volatile int *fk_ready = nullptr, int substep_no = 0) {
+                            volatile int *fk_ready = nullptr, int substep_no = 0, SelfLds<T> *sc = nullptr, bool last = true) {
     constexpr int K = T::K, L = T::L, NPT = T::NPT;
     const lg_params &P = A.P;
     const float dt = P.sim_dt;
@@ -330,6 +496,11 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, int lane_k, float 
                 cl[i].depth = tp[3];                                     // radius, for now
                 cl[i].vtn = root[2] + pw.z;                              // point height, for now
                 fl[i] = hf_fetch<HF>(A, root[0] + pw.x, root[1] + pw.y);
+                if (SC) {                                                // publish the sphere to the env's other lanes
+                    const int ln = threadIdx.x % LG_BLOCK;
+                    sc->pos[i][ln] = make_float4(pw.x, pw.y, pw.z, tp[3]);
+                    sc->vel[i][ln] = make_float4(cl[i].vc.x, cl[i].vc.y, cl[i].vc.z, 0.0f);
+                }
             }
             Rpar = Rj; rpar = rj; wpar = wj; vpar = vj;
         }
@@ -353,6 +524,8 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, int lane_k, float 
 #pragma unroll
         for (int j = 0; j < L; j++) bt_load(bt[j], threadIdx.x % LG_BLOCK, I0[j], p0[j]);
     }
+    bool any_self = false;                                 // wave-uniform
+    if (SC) any_self = self_collide<T>(A, tab, threadIdx.x % LG_BLOCK, root, db, I0, p0, *sc);
     LG_PROF(PF_TORQUE);
     // ---- articulated-body passes with the contact impedances folded in
     S6 U[L], acc0;
@@ -397,6 +570,13 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, int lane_k, float 
         }
         LG_PROF(PF_INWARD);
         contact_assemble(cb, P, kn, Ia, pa);      // this lane's base point (about the base origin, like Ia after the shift)
+        if (SC && any_self) {                     // reaction of this limb's deepest base contact: force -n f0 on the base, implicit in the base's motion
+            const float4 s0 = sc->base[0][threadIdx.x % LG_BLOCK], s1 = sc->base[1][threadIdx.x % LG_BLOCK];
+            if (s0.w > -1e29f) {
+                ai_add_rank1(Ia, dt * kn, xyz(s0), xyz(s1));
+                pa.w = pa.w + xyz(s0) * s1.w; pa.v = pa.v + xyz(s1) * s1.w;
+            }
+        }
         group_sum<K>(Ia, pa);                     // (limb0+limb1)+(limb2+limb3) on every lane of the env
         AI IAb = I0b; S6 pAb = p0b;
         ai_add(IAb, Ia); pAb = pAb + pa;
@@ -455,6 +635,17 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, int lane_k, float 
         Frep[r][0] = f.x; Frep[r][1] = f.y; Frep[r][2] = f.z;
     }
     Fbase[0] = group_sum<K>(cb.f.x); Fbase[1] = group_sum<K>(cb.f.y); Fbase[2] = group_sum<K>(cb.f.z);
+    if (SC && last && any_self) {                 // exported net contact forces include the self-collision forces
+        const int ln = threadIdx.x % LG_BLOCK;
+#pragma unroll
+        for (int c = 0; c < T::NCAP; c++) {
+            const float4 f = sc->frc[c][ln];
+            const int r = T::pt_rep(T::cap_p0(c));
+            Frep[r][0] += f.x; Frep[r][1] += f.y; Frep[r][2] += f.z;
+        }
+        const float4 fb = sc->frc[T::NCAP][ln];
+        Fbase[0] += group_sum<K>(fb.x); Fbase[1] += group_sum<K>(fb.y); Fbase[2] += group_sum<K>(fb.z);
+    }
     LG_PROF(PF_INTEGRATE);
 }
 
@@ -853,7 +1044,11 @@ template <class T, bool NET, bool HF, int NW> struct HelperWave {
 // NW = waves per workgroup (1 rigid-body wave + NW-1 helpers).  Every wave of the kernel gets the rigid-body wave's 512
 // registers, so a CU holds NW waves = one workgroup at a time: the host picks the largest NW in {4, 2, 1} that still fits
 // all workgroups on the chip in one round (256 workgroups -> 4; Cassie at 8192 envs = 512 workgroups -> 2).
-template <class T, bool NET, bool HF, bool POL = false, int NW = LG_STEP_WAVES>
+template <bool SC, class T> struct SelfStore { char unused; LG_DEV SelfLds<T> *get() { return nullptr; } };
+template <class T> struct SelfStore<true, T> { SelfLds<T> lds; LG_DEV SelfLds<T> *get() { return &lds; } };
+
+// SC: self-collision between the robot's own links (asset.self_collisions = 0; compiled for the quadruped layouts)
+template <class T, bool NET, bool HF, bool POL = false, int NW = LG_STEP_WAVES, bool SC = false>
 __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
     static_assert(!NET || (NW == LG_STEP_WAVES && 1 + T::L == NW), "one actuator wave per joint of the limb");
     static_assert(!POL || (NET && NW == LG_POLICY_WAVES && T::K * T::L <= 16), "fused policy needs the four-wave actuator-net kernel");
@@ -865,6 +1060,7 @@ __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
     __shared__ float lds_tau[NET ? L : 1][LG_BLOCK];            // actuator torques of the sub-step
     constexpr bool OFF = NW >= 2;
     __shared__ StepSharedT<OFF, L> sh;
+    __shared__ SelfStore<SC, T> sc_store;
     __shared__ int s_last;
     __shared__ float4 pol_xa[POL ? 4 : 1][64], pol_xb[POL ? 8 : 1][64], pol_xy[1][64];
     __shared__ float lds_act[POL ? 16 : 1][16];                 // sampled actions [action][env in block]
@@ -938,9 +1134,11 @@ __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
                     for (int j = 0; j < L; j++) tau[j] = lds_tau[j][lane];
                 }
             };
-            physics_substep<T, HF, decltype(join), OFF>(A, tab, k, root, q, qd, tau, base_mass, mu, Frep, Fbase, join, sh.bt, sh.fk, &sh.fk_ready, it + 1);
+            physics_substep<T, HF, decltype(join), OFF, SC>(A, tab, k, root, q, qd, tau, base_mass, mu, Frep, Fbase, join, sh.bt, sh.fk, &sh.fk_ready, it + 1,
+                                                            sc_store.get(), it == P.decimation - 1);
         } else {
-            physics_substep<T, HF>(A, tab, k, root, q, qd, tau, base_mass, mu, Frep, Fbase);
+            physics_substep<T, HF, NoWait, false, SC>(A, tab, k, root, q, qd, tau, base_mass, mu, Frep, Fbase, NoWait(), nullptr, nullptr, nullptr, 0,
+                                                      sc_store.get(), it == P.decimation - 1);
         }
     }
 
@@ -1252,11 +1450,12 @@ __global__ void __launch_bounds__(64) k_actuator(const float *table, const float
     if (live) torques[r] = t;
 }
 
-template <class T, bool HF>
+template <class T, bool HF, bool SC = false>
 __global__ void __launch_bounds__(LG_BLOCK) k_physics(const KArgs A, const float *torques, int write_contacts) {
     constexpr int K = T::K, L = T::L, ND = K * L, NREP = T::NREP;
     const lg_buffers &B = A.B;
     __shared__ float lds_tab[T::K * Tab<T>::STRIDE];
+    __shared__ SelfStore<SC, T> sc_store;
     stage_limb_table<T>(A, lds_tab);
     const int N = A.P.num_envs;
     const int tid = blockIdx.x * LG_BLOCK + threadIdx.x;
@@ -1281,7 +1480,7 @@ __global__ void __launch_bounds__(LG_BLOCK) k_physics(const KArgs A, const float
         Fbase[0] = c0[0]; Fbase[1] = c0[1]; Fbase[2] = c0[2];
     }
     write_contacts = 1;           // the net contact forces also seed the next sub-step's friction estimate
-    physics_substep<T, HF>(A, tab, k, root, q, qd, tau, base_mass, mu, Frep, Fbase);
+    physics_substep<T, HF, NoWait, false, SC>(A, tab, k, root, q, qd, tau, base_mass, mu, Frep, Fbase, NoWait(), nullptr, nullptr, nullptr, 0, sc_store.get(), true);
     if (!live) return;
 #pragma unroll
     for (int j = 0; j < L; j++) { B.dof_state[2 * (d0 + j)] = q[j]; B.dof_state[2 * (d0 + j) + 1] = qd[j]; }
@@ -1379,7 +1578,40 @@ template <class T> static void fill_limb_table(const lg_params &P, const lg_robo
             float *tp = tk + T::L * LG_JS + 4 * i;
             memcpy(tp, M.limb_points[k][i].pos, 12); tp[3] = M.limb_points[k][i].radius;
         }
+        for (int g = 0; g < T::NGRP; g++) {        // bounding sphere of each self-collision point group about the midpoint of its two anchor points
+            const float *a = M.limb_points[k][T::grp_c0(g)].pos, *b = M.limb_points[k][T::grp_c1(g)].pos;
+            const float c[3] = {0.5f * (a[0] + b[0]), 0.5f * (a[1] + b[1]), 0.5f * (a[2] + b[2])};
+            float R = 0.0f;
+            for (int cap = 0; cap < T::NCAP; cap++) if (T::cap_grp(cap) == g)
+                for (int e = 0; e < 2; e++) {
+                    const lg_point &pt = M.limb_points[k][e ? T::cap_p1(cap) : T::cap_p0(cap)];
+                    const float dx = pt.pos[0] - c[0], dy = pt.pos[1] - c[1], dz = pt.pos[2] - c[2];
+                    R = fmaxf(R, sqrtf(dx * dx + dy * dy + dz * dz) + pt.radius);
+                }
+            tk[Tab<T>::GRP + g] = R * 1.0001f;
+        }
     }
+}
+
+// self-collision shapes: the oracle pairs consecutive points (same body, radius, report body) into capsules at run time; the kernels
+// have the pairing compiled in (Traits::cap_p0 / cap_p1).  Accept the model only if both views agree.
+template <class T> static int check_capsules(const lg_robot_model *m) {
+    auto mergeable = [](const lg_point &a, const lg_point &b) { return a.joint == b.joint && a.radius == b.radius && a.report_body == b.report_body; };
+    for (int k = 0; k < T::K; k++) {
+        int next = 0;
+        for (int c = 0; c < T::NCAP; c++) {
+            const int p0 = T::cap_p0(c), p1 = T::cap_p1(c);
+            if (p0 != next) return 0;
+            if (p1 != p0 && !(p1 == p0 + 1 && mergeable(m->limb_points[k][p0], m->limb_points[k][p1]))) return 0;
+            if (p1 == p0 && p0 + 1 < T::NPT && mergeable(m->limb_points[k][p0], m->limb_points[k][p0 + 1])) return 0;
+            if (T::pt_joint(p0) != T::pt_joint(p1)) return 0;
+            next = p1 + 1;
+        }
+        if (next != T::NPT) return 0;
+    }
+    for (int i = 0; i < m->num_base_points; i += 2)        // base: pairs (0,1), (2,3); an odd last point is a sphere
+        if (i + 1 < m->num_base_points && m->base_points[i].radius != m->base_points[i + 1].radius) return 0;
+    return 1;
 }
 
 // Per-lane MFMA operand table of the actuator net (layout: lg_device.h "ANYdrive actuator net").
@@ -1870,6 +2102,8 @@ int lg_create(const lg_params *params, const lg_robot_model *model, const float 
     else return fail(-4, "robot topology is not one of the compiled-in layouts (ANYmal-C 4x3, Cassie 2x6)");
     if (params->control_type == LG_CTRL_ACTUATOR_NET && !actuator_weights) return fail(-2, "actuator-net control without weights");
     if (params->control_type == LG_CTRL_ACTUATOR_NET && kind != ROBOT_ANYMAL) return fail(-2, "actuator net is compiled for the ANYmal layout only");
+    if (params->self_collision && kind != ROBOT_ANYMAL) return fail(-4, "self-collision (asset.self_collisions = 0) is compiled for the quadruped layouts only");
+    if (params->self_collision && !check_capsules<AnymalTraits>(model)) return fail(-4, "collision points do not form the compiled-in capsule layout (self-collision)");
     HIP_TRY(hipSetDevice(device_id));
     lg_sim *s = new (std::nothrow) lg_sim();
     if (!s) return fail(-5, "out of host memory");
@@ -1935,10 +2169,10 @@ int lg_set_params(lg_sim *s, const lg_params *p) {
 
 // helper waves only pay off while every workgroup still gets a CU of its own in one round (all waves carry 512 registers)
 static int waves_for(unsigned workgroups, int num_cus) { return workgroups <= (unsigned)num_cus ? 4 : (workgroups <= 2u * num_cus ? 2 : 1); }
-#define LAUNCH_NW(TRAITS, HFV)                                                                                                   \
-    { if (nw == 4) hipLaunchKernelGGL((k_step<TRAITS, false, HFV, false, 4>), g, dim3(4 * LG_BLOCK), 0, st, a);                  \
-      else if (nw == 2) hipLaunchKernelGGL((k_step<TRAITS, false, HFV, false, 2>), g, dim3(2 * LG_BLOCK), 0, st, a);             \
-      else hipLaunchKernelGGL((k_step<TRAITS, false, HFV, false, 1>), g, dim3(LG_BLOCK), 0, st, a); }
+#define LAUNCH_NW(TRAITS, HFV, SCV)                                                                                              \
+    { if (nw == 4) hipLaunchKernelGGL((k_step<TRAITS, false, HFV, false, 4, SCV>), g, dim3(4 * LG_BLOCK), 0, st, a);             \
+      else if (nw == 2) hipLaunchKernelGGL((k_step<TRAITS, false, HFV, false, 2, SCV>), g, dim3(2 * LG_BLOCK), 0, st, a);        \
+      else hipLaunchKernelGGL((k_step<TRAITS, false, HFV, false, 1, SCV>), g, dim3(LG_BLOCK), 0, st, a); }
 
 int lg_step(lg_sim *s, const float *actions, int64_t common_step_counter, void *stream) {
     if (!s || !s->bound) return fail(-8, "lg_bind has not been called");
@@ -1951,15 +2185,18 @@ int lg_step(lg_sim *s, const float *actions, int64_t common_step_counter, void *
     if (s->kind == ROBOT_ANYMAL) {
         dim3 g(grid_for<AnymalTraits>(s->P.num_envs)), b(LG_STEP_WAVES * LG_BLOCK);
         const int nw = net ? LG_STEP_WAVES : waves_for(g.x, s->num_cus);
-        if (net && !hf) hipLaunchKernelGGL((k_step<AnymalTraits, true, false>), g, b, 0, st, a);
-        else if (net && hf) hipLaunchKernelGGL((k_step<AnymalTraits, true, true>), g, b, 0, st, a);
-        else if (!hf) LAUNCH_NW(AnymalTraits, false)
-        else LAUNCH_NW(AnymalTraits, true)
+        const bool sc = s->P.self_collision != 0;
+        if (net && !hf) { if (sc) hipLaunchKernelGGL((k_step<AnymalTraits, true, false, false, 4, true>), g, b, 0, st, a);
+                          else hipLaunchKernelGGL((k_step<AnymalTraits, true, false>), g, b, 0, st, a); }
+        else if (net && hf) { if (sc) hipLaunchKernelGGL((k_step<AnymalTraits, true, true, false, 4, true>), g, b, 0, st, a);
+                              else hipLaunchKernelGGL((k_step<AnymalTraits, true, true>), g, b, 0, st, a); }
+        else if (!hf) { if (sc) LAUNCH_NW(AnymalTraits, false, true) else LAUNCH_NW(AnymalTraits, false, false) }
+        else { if (sc) LAUNCH_NW(AnymalTraits, true, true) else LAUNCH_NW(AnymalTraits, true, false) }
     } else {
         dim3 g(grid_for<CassieTraits>(s->P.num_envs));
         const int nw = waves_for(g.x, s->num_cus);
-        if (!hf) LAUNCH_NW(CassieTraits, false)
-        else LAUNCH_NW(CassieTraits, true)
+        if (!hf) LAUNCH_NW(CassieTraits, false, false)
+        else LAUNCH_NW(CassieTraits, true, false)
     }
     HIP_TRY(hipGetLastError());
     return 0;
@@ -1976,8 +2213,12 @@ int lg_step_policy(lg_sim *s, lg_policy *p, const float *obs, float *actions, fl
         return fail(-4, "the fused policy step is compiled for the 48-128-64-32 actor on the quadruped actuator-net plane kernel; use lg_policy_act + lg_step");
     KArgs a; fill_args(s, a, common_step_counter); a.actions_in = nullptr;
     fill_policy_args(p, a.pol, obs, actions, mean, s->P.num_envs, seed, common_step_counter, s->B.step_counter, deterministic);
-    hipLaunchKernelGGL((k_step<AnymalTraits, true, false, true>), dim3(grid_for<AnymalTraits>(s->P.num_envs)), dim3(LG_STEP_WAVES * LG_BLOCK),
-                       0, (hipStream_t)stream, a);
+    if (s->P.self_collision)
+        hipLaunchKernelGGL((k_step<AnymalTraits, true, false, true, 4, true>), dim3(grid_for<AnymalTraits>(s->P.num_envs)), dim3(LG_STEP_WAVES * LG_BLOCK),
+                           0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL((k_step<AnymalTraits, true, false, true>), dim3(grid_for<AnymalTraits>(s->P.num_envs)), dim3(LG_STEP_WAVES * LG_BLOCK),
+                           0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -2017,7 +2258,10 @@ int lg_physics_substep(lg_sim *s, const float *torques, int32_t write_contacts, 
     const bool hf = s->P.terrain_type == LG_TERRAIN_HEIGHTFIELD;
     if (s->kind == ROBOT_ANYMAL) {
         dim3 g(grid_for<AnymalTraits>(s->P.num_envs)), b(LG_BLOCK);
-        if (hf) hipLaunchKernelGGL((k_physics<AnymalTraits, true>), g, b, 0, st, a, torques, write_contacts);
+        if (s->P.self_collision) {
+            if (hf) hipLaunchKernelGGL((k_physics<AnymalTraits, true, true>), g, b, 0, st, a, torques, write_contacts);
+            else hipLaunchKernelGGL((k_physics<AnymalTraits, false, true>), g, b, 0, st, a, torques, write_contacts);
+        } else if (hf) hipLaunchKernelGGL((k_physics<AnymalTraits, true>), g, b, 0, st, a, torques, write_contacts);
         else hipLaunchKernelGGL((k_physics<AnymalTraits, false>), g, b, 0, st, a, torques, write_contacts);
     } else {
         dim3 g(grid_for<CassieTraits>(s->P.num_envs)), b(LG_BLOCK);

@@ -232,9 +232,6 @@ class LeggedRobot(BaseTask):
                                       replace_cylinder_with_capsule=cfg.asset.replace_cylinder_with_capsule) \
             if os.path.isfile(asset_path) else load_model(asset_path)
         rm = self.robot_model
-        if int(getattr(cfg.asset, "self_collisions", 1)) == 0 and not getattr(LeggedRobot, "_warned_self_collision", False):
-            LeggedRobot._warned_self_collision = True     # e.g. anymal_c_flat (anymal_c_flat_config.py:42); DESIGN.md section 3, known limits
-            print("[legged_games_gym_amd] asset.self_collisions = 0 (enabled) is not modelled by this engine: links of one robot do not collide with each other")
         self.num_dof = self.num_dofs = rm.num_dof
         self.num_bodies = rm.num_bodies
         self.dof_names = list(rm.dof_names)
@@ -250,6 +247,8 @@ class LeggedRobot(BaseTask):
         self._params, self.reward_names_all = packing.build_params(
             cfg, rm, sim_dt, self.num_envs, seed if seed is not None and seed >= 0 else 1, gravity=gravity,
             terrain=self.terrain, contact_offset=contact_offset)
+        # asset.self_collisions = 0 (e.g. anymal_c_flat, anymal_c_flat_config.py:42): links of one robot collide (DESIGN.md "Self-collision")
+        self.self_collision_modelled = bool(self._params.self_collision)
         self._model = capi.pack_model(rm, cfg.asset.foot_name, cfg.asset.penalize_contacts_on,
                                       cfg.asset.terminate_after_contacts_on, armature=cfg.asset.armature)
         weights = None

@@ -147,6 +147,8 @@ def build_params(cfg, model, sim_dt: float, num_envs: int, seed: int, gravity=(0
         p.terrain_env_length = cfg.terrain.terrain_length
     else:
         p.terrain_type, p.custom_origins, p.terrain_curriculum = capi.TERRAIN_PLANE, 0, 0
+    # asset.self_collisions is Isaac Gym's collision-filter bitmask: 0 = links of the robot collide with each other (legged_robot.py:683)
+    p.self_collision = int(int(getattr(cfg.asset, "self_collisions", 1)) == 0)
     init = cfg.init_state
     capi._fill(p.base_init_state, list(init.pos) + list(init.rot) + list(init.lin_vel) + list(init.ang_vel))
     p.seed = int(seed) & 0xFFFFFFFFFFFFFFFF

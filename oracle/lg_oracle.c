@@ -277,6 +277,86 @@ static inline float motor_torque(float tau, float qd, float vlim) {
     return tau * fminf(fmaxf(s, 0.0f), 1.0f);
 }
 
+
+/* ------------------------------------------------------------------ self-collision (asset.self_collisions = 0, legged_robot.py:683)
+ * PhysX collides the links of one articulation with each other when the asset's collision filter is 0 (anymal_c_flat_config.py:42),
+ * except directly connected links.  The built-in engine's version (DESIGN.md "Self-collision"), defined here:
+ *   - shapes: consecutive collision points on the same body with equal radius form a capsule (segment + radius), a single
+ *     point is a sphere (ANYmal-C limb: KFE-drive capsule on the THIGH, shank capsule, foot sphere; base capsule);
+ *   - pairs: every limb capsule against the base capsules and against the capsules of every OTHER limb (links of one limb
+ *     are adjacent or out of each other's reach); closest points of the two segments, depth = ra + rb - distance;
+ *   - force: frictionless implicit spring-damper along the contact normal, f = max(0, K d - kappa v_n) with v_n the relative
+ *     normal velocity at the start of the sub-step; active for d > -contact_margin and f > 0;
+ *   - coupling: each body treats the other as moving with its start-of-step velocity (block Jacobi): the limb body gets
+ *     dt kappa g g^T added to its rigid-body inertia and -J^T f to its bias force before the articulated-body passes; the
+ *     base gets the reaction of each limb's DEEPEST base contact the same way (it rides with that limb's partial sums);
+ *   - contact_forces: the exported net contact force of a body includes its self-collision forces (as PhysX's does). */
+typedef struct { v3 a0, a1, va0, va1; float rad; int body, report; } capsule_t;
+
+static void seg_seg_closest(v3 a0, v3 a1, v3 b0, v3 b1, float *ps, float *pt) {
+    /* closest points a0 + s (a1 - a0), b0 + t (b1 - b0), s, t in [0,1] (Ericson, Real-Time Collision Detection 5.1.9) */
+    const float eps = 1e-12f;
+    v3 d1 = sub(a1, a0), d2 = sub(b1, b0), r = sub(a0, b0);
+    float a = dot(d1, d1), e = dot(d2, d2), f = dot(d2, r), s, t;
+    if (a <= eps && e <= eps) { s = 0.0f; t = 0.0f; }
+    else if (a <= eps) { s = 0.0f; t = fminf(fmaxf(f / e, 0.0f), 1.0f); }
+    else {
+        float c = dot(d1, r);
+        if (e <= eps) { t = 0.0f; s = fminf(fmaxf(-c / a, 0.0f), 1.0f); }
+        else {
+            float b = dot(d1, d2), denom = a * e - b * b;
+            s = (denom > eps) ? fminf(fmaxf((b * f - c * e) / denom, 0.0f), 1.0f) : 0.0f;
+            t = (b * s + f) / e;
+            if (t < 0.0f) { t = 0.0f; s = fminf(fmaxf(-c / a, 0.0f), 1.0f); }
+            else if (t > 1.0f) { t = 1.0f; s = fminf(fmaxf((b - c) / a, 0.0f), 1.0f); }
+        }
+    }
+    *ps = s; *pt = t;
+}
+
+/* capsules of one point group (base: g < 0, else limb g); positions relative to the base origin, world axes */
+static int build_capsules(const lg_robot_model *M, int g, int L, const float (*Rb)[9], const v3 *rb, const v3 *wb, const v3 *vb, capsule_t *out) {
+    int np = (g < 0) ? M->num_base_points : M->num_limb_points[g], n = 0;
+    for (int i = 0; i < np; ) {
+        const lg_point *p0 = (g < 0) ? &M->base_points[i] : &M->limb_points[g][i];
+        int b = (g < 0) ? 0 : 1 + g * L + p0->joint, j = i;
+        if (i + 1 < np) {
+            const lg_point *p1 = (g < 0) ? &M->base_points[i + 1] : &M->limb_points[g][i + 1];
+            if (p1->joint == p0->joint && p1->radius == p0->radius && p1->report_body == p0->report_body) j = i + 1;
+        }
+        const lg_point *p1 = (g < 0) ? &M->base_points[j] : &M->limb_points[g][j];
+        capsule_t *c = &out[n++];
+        v3 r0 = mv(Rb[b], V(p0->pos[0], p0->pos[1], p0->pos[2])), r1 = mv(Rb[b], V(p1->pos[0], p1->pos[1], p1->pos[2]));
+        c->a0 = add(rb[b], r0); c->a1 = add(rb[b], r1);
+        c->va0 = add(vb[b], cross(wb[b], r0)); c->va1 = add(vb[b], cross(wb[b], r1));
+        c->rad = p0->radius; c->body = b; c->report = p0->report_body;
+        i = j + 1;
+    }
+    return n;
+}
+
+typedef struct { int on; float depth, f0; v3 cxn, n; } base_slot_t;     /* reaction of a limb's deepest base contact */
+
+/* one capsule pair: A (on a limb body) against B.  Returns 1 and fills (n: from B to A, depth, f0, contact points) when active. */
+static int capsule_contact(const lg_params *P, const capsule_t *A, const capsule_t *B, float kn, v3 *n, float *depth, float *f0, v3 *pa, v3 *pb) {
+    float s, t;
+    seg_seg_closest(A->a0, A->a1, B->a0, B->a1, &s, &t);
+    v3 ca = add(A->a0, scl(sub(A->a1, A->a0), s)), cb = add(B->a0, scl(sub(B->a1, B->a0), t));
+    v3 diff = sub(ca, cb);
+    float dist = sqrtf(dot(diff, diff));
+    float d = A->rad + B->rad - dist;
+    if (!(d > -P->contact_margin)) return 0;
+    *n = scl(diff, 1.0f / fmaxf(dist, 1e-9f));
+    v3 va = add(A->va0, scl(sub(A->va1, A->va0), s)), vbv = add(B->va0, scl(sub(B->va1, B->va0), t));
+    float vn = dot(*n, sub(va, vbv));
+    float f = P->contact_stiffness * d - kn * vn;
+    if (!(f > 0.0f)) return 0;
+    *depth = d; *f0 = f;
+    *pa = sub(ca, scl(*n, A->rad));              /* contact point on A's surface */
+    *pb = add(cb, scl(*n, B->rad));              /* ... on B's surface */
+    return 1;
+}
+
 /* ------------------------------------------------------------------ physics sub-step (stands in for legged_robot.py:92-96) */
 #define NB (1 + LG_MAX_DOF)
 #define NPTS (LG_MAX_BASE_POINTS + LG_MAX_LIMBS * LG_MAX_LIMB_POINTS)
@@ -385,6 +465,40 @@ static void physics_substep_env(const lgo_sim *s, int e, const float *tau, int w
         p0[b].v = sub(cross(wb[b], l), fg);
     }
 
+    /* ---- self-collision: folded into the rigid-body terms of the limb bodies; base reactions kept per limb */
+    base_slot_t bslot[LG_MAX_LIMBS];
+    float self_cf[LG_MAX_BODIES][3];
+    memset(self_cf, 0, sizeof self_cf);
+    for (int k = 0; k < K; k++) bslot[k].on = 0;
+    if (P->self_collision) {
+        const float kn_s = P->contact_stiffness * dt + P->contact_damping;
+        capsule_t cbase[LG_MAX_BASE_POINTS], climb[LG_MAX_LIMBS][LG_MAX_LIMB_POINTS];
+        int nbase = build_capsules(M, -1, L, Rb, rb, wb, vb, cbase), nl[LG_MAX_LIMBS];
+        for (int k = 0; k < K; k++) nl[k] = build_capsules(M, k, L, Rb, rb, wb, vb, climb[k]);
+        for (int k = 0; k < K; k++) {
+            for (int m = 0; m < K; m++) {              /* m = 0: the base; m > 0: limb k ^ m (the lane's DPP partner order) */
+                const capsule_t *other = (m == 0) ? cbase : climb[k ^ m];
+                int no = (m == 0) ? nbase : nl[k ^ m];
+                if (m > 0 && (k ^ m) >= K) continue;
+                for (int i = 0; i < nl[k]; i++) for (int j = 0; j < no; j++) {
+                    const capsule_t *A = &climb[k][i];
+                    v3 n, pa, pb; float depth, f0;
+                    if (!capsule_contact(P, A, &other[j], kn_s, &n, &depth, &f0, &pa, &pb)) continue;
+                    v3 r = sub(pa, rb[A->body]);                          /* arm about the body's own joint origin */
+                    ai_add_rank1(&I0[A->body], dt * kn_s, cross(r, n), n);
+                    v3 f = scl(n, f0);
+                    p0[A->body].w = sub(p0[A->body].w, cross(r, f));
+                    p0[A->body].v = sub(p0[A->body].v, f);
+                    self_cf[A->report][0] += f.x; self_cf[A->report][1] += f.y; self_cf[A->report][2] += f.z;
+                    if (m == 0 && (!bslot[k].on || depth > bslot[k].depth)) {
+                        bslot[k].on = 1; bslot[k].depth = depth; bslot[k].f0 = f0; bslot[k].n = n; bslot[k].cxn = cross(pb, n);
+                    }
+                }
+            }
+            if (bslot[k].on) { self_cf[0][0] -= bslot[k].n.x * bslot[k].f0; self_cf[0][1] -= bslot[k].n.y * bslot[k].f0; self_cf[0][2] -= bslot[k].n.z * bslot[k].f0; }
+        }
+    }
+
     /* ---- contact candidates (r is relative to the carrying body's O_b) */
     contact_t ct[NPTS];
     int nc = 0;
@@ -442,6 +556,12 @@ static void physics_substep_env(const lgo_sim *s, int e, const float *tau, int w
             ai_add_rank1(It, dt * (c->kn - c->bt), cross(c->r, c->n), c->n);
             pt_->w = sub(pt_->w, cross(c->r, f));
             pt_->v = sub(pt_->v, f);
+        }
+        for (int k = 0; k < K; k++) if (bslot[k].on) {      /* reaction of limb k's deepest base contact: force -n f on the base */
+            const float kn_s = P->contact_stiffness * dt + P->contact_damping;
+            ai_add_rank1(&IBp[k], dt * kn_s, bslot[k].cxn, bslot[k].n);
+            pBp[k].w = add(pBp[k].w, scl(bslot[k].cxn, bslot[k].f0));
+            pBp[k].v = add(pBp[k].v, scl(bslot[k].n, bslot[k].f0));
         }
         for (int k = 0; k < K; k++) for (int j = L - 1; j >= 0; j--) {
             int d = k * L + j, b = 1 + d, par = (j == 0) ? 0 : b - 1;
@@ -545,11 +665,15 @@ static void physics_substep_env(const lgo_sim *s, int e, const float *tau, int w
         float inv = 1.0f / sqrtf(nx * nx + ny * ny + nz * nz + nw * nw);
         root[3] = nx * inv; root[4] = ny * inv; root[5] = nz * inv; root[6] = nw * inv;
     }
-    (void)write_contacts;       /* always: the net contact forces also seed the next sub-step's friction estimate */
+    /* always written: the net GROUND contact forces also seed the next sub-step's friction estimate.  `write_contacts` (the
+     * last sub-step of a policy step, or the sub-step entry point) adds the self-collision forces: that sum is what the
+     * net-contact-force tensor exports (termination, collision penalty). */
     {
         float *cf = s->B.contact_forces + (size_t)e * M->num_bodies * 3;
         for (int i = 0; i < M->num_bodies * 3; i++) cf[i] = 0.0f;
         for (int i = 0; i < nc; i++) { cf[3 * ct[i].report] += ct[i].f.x; cf[3 * ct[i].report + 1] += ct[i].f.y; cf[3 * ct[i].report + 2] += ct[i].f.z; }
+        if (write_contacts && P->self_collision)
+            for (int b = 0; b < M->num_bodies; b++) for (int i = 0; i < 3; i++) cf[3 * b + i] += self_cf[b][i];
     }
 }
 

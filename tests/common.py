@@ -105,3 +105,44 @@ def golden_tweak(kind):
         if kind.startswith("pd_"):
             cfg.control.control_type = kind[3:]
     return tweak
+
+
+def robot_capsules(robot, q):
+    """Collision capsules of the robot at joint angles ``q`` in the BASE frame, float64, independent of the engine code:
+    list of (owner, a0, a1, radius) with owner = -1 for the base and k for limb k.  Consecutive collision points on the same
+    body with equal radius and report body form a capsule; a lone point is a sphere (a0 == a1)."""
+    Rs, ps = robot.forward_kinematics(q)
+    out = []
+
+    def group(points, joints, owner, frame):
+        i = 0
+        while i < len(points):
+            j = i
+            if i + 1 < len(points) and joints[i + 1] == joints[i] and points[i + 1].radius == points[i].radius \
+                    and points[i + 1].report_body == points[i].report_body:
+                j = i + 1
+            R, p = frame(joints[i])
+            out.append((owner, p + R @ np.asarray(points[i].pos, float), p + R @ np.asarray(points[j].pos, float), float(points[i].radius)))
+            i = j + 1
+    group(robot.base_points, [-1] * len(robot.base_points), -1, lambda j: (np.eye(3), np.zeros(3)))
+    L = robot.chain_len
+    for k in range(robot.num_limbs):
+        group(robot.limb_points[k], list(robot.limb_point_joint[k]), k, lambda j, k=k: (Rs[k * L + j], ps[k * L + j]))
+    return out
+
+
+def min_self_clearance(robot, q, samples=33):
+    """Smallest gap (negative = interpenetration depth) between capsules of different owners (limb-limb and limb-base), by
+    brute-force sampling of both segments -- deliberately not the closed-form routine the engine uses."""
+    caps = robot_capsules(robot, q)
+    t = np.linspace(0.0, 1.0, samples)[:, None]
+    best = np.inf
+    for i in range(len(caps)):
+        for j in range(i + 1, len(caps)):
+            if caps[i][0] == caps[j][0]:
+                continue
+            A = caps[i][1] + t * (caps[i][2] - caps[i][1])
+            B = caps[j][1] + t * (caps[j][2] - caps[j][1])
+            d = np.sqrt(((A[:, None, :] - B[None, :, :]) ** 2).sum(-1)).min()
+            best = min(best, d - caps[i][3] - caps[j][3])
+    return best

@@ -201,3 +201,90 @@ def test_non_finite_state_forces_a_reset(oracle_lib):
     o.buf["root_states"][2, 8] = np.nan
     o.step(np.zeros((4, 12), np.float32), 2)
     assert o.buf["reset_buf"].tolist() == [0, 0, 1, 0] and np.isfinite(o.buf["root_states"]).all() and np.isfinite(o.buf["obs_buf"]).all()
+
+
+# ------------------------------------------------------------------ self-collision (asset.self_collisions = 0: anymal_c_flat_config.py:42)
+def _crossing_pose(robot, q0):
+    """Joint angles that push the left-front and right-front lower legs a centimetre INTO each other (found numerically with the
+    independent capsule model of tests/common.py: sweep both HAA joints inwards from the default pose)."""
+    from tests.common import min_self_clearance
+    names = list(robot.dof_names)
+    lf, rf = names.index("LF_HAA"), names.index("RF_HAA")
+    sign = {}
+    for d in (lf, rf):                       # which direction swings that leg towards the other one?
+        qa, qb = q0.copy(), q0.copy()
+        qa[d] += 0.5; qb[d] -= 0.5
+        sign[d] = 1.0 if min_self_clearance(robot, qa) < min_self_clearance(robot, qb) else -1.0
+    lo, hi = 0.0, 1.5
+    for _ in range(30):                      # bisection on the common inward angle: clearance(mid) = -1 cm
+        mid = 0.5 * (lo + hi)
+        q = q0.copy(); q[lf] += sign[lf] * mid; q[rf] += sign[rf] * mid
+        if min_self_clearance(robot, q) > -0.01:
+            lo = mid
+        else:
+            hi = mid
+    q = q0.copy(); q[lf] += sign[lf] * hi; q[rf] += sign[rf] * hi
+    return q, sign, (lf, rf)
+
+
+def test_self_collision_pushes_crossed_legs_apart(oracle_lib):
+    from tests.common import min_self_clearance
+    outs = {}
+    for on in (1, 0):
+        cfg, robot, p, o = sim("anymal_c_flat", 2, tweak=lambda c: setattr(c.asset, "self_collisions", 0 if on else 1))
+        assert p.self_collision == on
+        airborne(o)
+        q0 = np.array(list(p.default_dof_pos)[:12], np.float64)
+        q, sign, (lf, rf) = _crossing_pose(robot, q0)
+        assert -0.02 < min_self_clearance(robot, q) < -0.005
+        dof = o.buf["dof_state"].reshape(2, 12, 2)
+        dof[:, :, 0] = q; dof[:, :, 1] = 0.0
+        o.buf["root_states"][:, 3:7] = [0, 0, 0, 1]; o.buf["root_states"][:, 7:13] = 0.0
+        o.physics_substep(np.zeros((2, 12), np.float32), True)
+        outs[on] = (o.buf["contact_forces"].copy(), o.dof_vel.copy(), sign, lf, rf)
+    cf, qd, sign, lf, rf = outs[1]
+    bn = list(robot.body_names)
+    lower = lambda side: cf[0, bn.index(side + "_SHANK")] + cf[0, bn.index(side + "_FOOT")] + cf[0, bn.index(side + "_THIGH")]
+    f_l, f_r = lower("LF"), lower("RF")
+    # 1 cm of overlap on a 1e6 N/m contact: kilonewtons, equal and opposite between the two legs (each lane evaluates its own side)
+    assert np.linalg.norm(f_l) > 500.0 and np.linalg.norm(f_l + f_r) < 0.02 * np.linalg.norm(f_l)
+    assert f_l[1] > 0 and f_r[1] < 0                         # left leg pushed to +y (left), right leg to -y
+    # the HAA joints are driven back outwards, against the direction that closed the gap
+    assert qd[0, lf] * sign[lf] < -0.1 and qd[0, rf] * sign[rf] < -0.1
+    # switched off (anymal_c_rough_config.py:77): links pass through each other, no force, no motion beyond gravity's
+    cf0, qd0 = outs[0][0], outs[0][1]
+    assert np.abs(cf0).max() == 0.0 and abs(qd0[0, lf]) < 0.05
+
+
+def test_self_collision_prevents_interpenetration_under_adversarial_actions(oracle_lib):
+    """50 policy steps of actions that drive the legs into each other and into the trunk (HAA inwards, feet folded up against the
+    belly): with self-collision on, no capsule pair ends up overlapping by more than contact_offset (1 cm); switched off, the
+    same actions produce centimetres of overlap -- so the test is adversarial."""
+    from tests.common import min_self_clearance
+    worst = {}
+    for on in (1, 0):
+        cfg, robot, p, o = sim("anymal_c_flat", 8, tweak=lambda c: (setattr(c.asset, "self_collisions", 0 if on else 1),
+                                                                   setattr(c.noise, "add_noise", False), setattr(c.domain_rand, "push_robots", False)))
+        N = 8
+        o.reset_idx(np.arange(N, dtype=np.int32), 0)
+        q0 = np.array(list(p.default_dof_pos)[:12], np.float64)
+        _, sign, (lf, rf) = _crossing_pose(robot, q0)
+        names = list(robot.dof_names)
+        rng = np.random.default_rng(0)
+        act = np.zeros((N, 12), np.float32)
+        for d, nme in enumerate(names):
+            if nme.endswith("HAA"):                            # all four legs swing towards the body's mid-plane
+                side = 1.0 if nme.startswith("L") else -1.0
+                ref = sign[lf] if nme.startswith("L") else sign[rf]
+                act[:, d] = ref * rng.uniform(1.5, 3.0, N)     # x action_scale 0.5 = 0.75 .. 1.5 rad
+            if nme.endswith("KFE"):
+                act[:, d] = np.sign(q0[d]) * rng.uniform(1.0, 3.0, N)      # fold the knees further
+        mins = []
+        for it in range(1, 51):
+            o.step(act, it)
+            if it % 5 == 0:
+                mins.append(min(min_self_clearance(robot, o.dof_pos[e].astype(np.float64)) for e in range(N)))
+        assert np.isfinite(o.buf["root_states"]).all()
+        worst[on] = min(mins)
+    assert worst[0] < -0.03, worst                            # without it the legs interpenetrate
+    assert worst[1] > -(0.01 + 0.003), worst                  # with it: within contact_offset (+ fp / sampling slack)
