@@ -275,17 +275,17 @@ template <class T> struct SelfLds {
     float4 base[2][LG_BLOCK];            // reaction of the lane's deepest base contact: (c x n, depth), (n, f0); depth < -1e29: none
     float4 frc[T::NCAP + 1][LG_BLOCK];   // self-collision force on each capsule's report body, [NCAP]: this lane's share on the base
 };
-struct CapD { V3 a0, a1, v0, v1; float rad; };
 LG_DEV V3 xyz(float4 a) { return v3(a.x, a.y, a.z); }
-LG_DEV void seg_seg_closest(V3 a0, V3 a1, V3 b0, V3 b1, float &s, float &t) {     // Ericson, RTCD 5.1.9
+// closest points of two segments, parameters in [0,1] (Ericson, RTCD 5.1.9); SA / SB: that "segment" is a point (compile time)
+template <bool SA, bool SB> LG_DEV void seg_seg_closest(V3 a0, V3 a1, V3 b0, V3 b1, float &s, float &t) {
     const float eps = 1e-12f;
     V3 d1 = a1 - a0, d2 = b1 - b0, r = a0 - b0;
-    float a = dot(d1, d1), e = dot(d2, d2), f = dot(d2, r);
-    if (a <= eps && e <= eps) { s = 0.0f; t = 0.0f; }
-    else if (a <= eps) { s = 0.0f; t = fminf(fmaxf(f / e, 0.0f), 1.0f); }
+    float a = SA ? 0.0f : dot(d1, d1), e = SB ? 0.0f : dot(d2, d2), f = SB ? 0.0f : dot(d2, r);
+    if ((SA || a <= eps) && (SB || e <= eps)) { s = 0.0f; t = 0.0f; }
+    else if (SA || a <= eps) { s = 0.0f; t = fminf(fmaxf(f / e, 0.0f), 1.0f); }
     else {
         float c = dot(d1, r);
-        if (e <= eps) { t = 0.0f; s = fminf(fmaxf(-c / a, 0.0f), 1.0f); }
+        if (SB || e <= eps) { t = 0.0f; s = fminf(fmaxf(-c / a, 0.0f), 1.0f); }
         else {
             float b = dot(d1, d2), denom = a * e - b * b;
             s = (denom > eps) ? fminf(fmaxf((b * f - c * e) / denom, 0.0f), 1.0f) : 0.0f;
@@ -295,66 +295,63 @@ LG_DEV void seg_seg_closest(V3 a0, V3 a1, V3 b0, V3 b1, float &s, float &t) {   
         }
     }
 }
-LG_DEV bool capsule_contact(const lg_params &P, const CapD &A, const CapD &B, float kn, V3 &n, float &depth, float &f0, V3 &pa, V3 &pb) {
+struct SelfHit { V3 n, pa, pb; float depth, f0; };
+// One capsule pair: A = segment a0-a1 (radius ra) of this lane's limb, B = the other shape.  Geometry first; the velocities
+// (`vel`: callback returning the four end-point velocities) are only fetched for pairs within the contact margin.
+template <bool SA, bool SB, class Vel>
+LG_DEV bool capsule_contact(const lg_params &P, float kn, V3 a0, V3 a1, float ra, V3 b0, V3 b1, float rb, Vel vel, SelfHit &h) {
     float s, t;
-    seg_seg_closest(A.a0, A.a1, B.a0, B.a1, s, t);
-    V3 ca = A.a0 + (A.a1 - A.a0) * s, cb = B.a0 + (B.a1 - B.a0) * t, diff = ca - cb;
+    seg_seg_closest<SA, SB>(a0, a1, b0, b1, s, t);
+    V3 ca = a0 + (a1 - a0) * s, cb = b0 + (b1 - b0) * t, diff = ca - cb;
     float dist = sqrtf(dot(diff, diff));
-    float d = A.rad + B.rad - dist;
+    float d = ra + rb - dist;
     if (!(d > -P.contact_margin)) return false;
-    n = diff * (1.0f / fmaxf(dist, 1e-9f));
-    V3 va = A.v0 + (A.v1 - A.v0) * s, vb = B.v0 + (B.v1 - B.v0) * t;
-    float f = P.contact_stiffness * d - kn * dot(n, va - vb);
+    V3 va0, va1, vb0, vb1;
+    vel(va0, va1, vb0, vb1);
+    h.n = diff * (1.0f / fmaxf(dist, 1e-9f));
+    V3 va = va0 + (va1 - va0) * s, vb = vb0 + (vb1 - vb0) * t;
+    float f = P.contact_stiffness * d - kn * dot(h.n, va - vb);
     if (!(f > 0.0f)) return false;
-    depth = d; f0 = f; pa = ca - n * A.rad; pb = cb + n * B.rad;
+    h.depth = d; h.f0 = f; h.pa = ca - h.n * ra; h.pb = cb + h.n * rb;
     return true;
 }
-template <class T> LG_DEV CapD load_cap(const SelfLds<T> &sc, int lane, int p0, int p1) {
-    CapD c; float4 a = sc.pos[p0][lane], b = sc.pos[p1][lane];
-    c.a0 = xyz(a); c.a1 = xyz(b); c.rad = a.w; c.v0 = xyz(sc.vel[p0][lane]); c.v1 = xyz(sc.vel[p1][lane]);
-    return c;
-}
 // Returns (wave-uniform) whether any lane of the wave went through the narrow phase: only then do sc.base / sc.frc hold data.
+// gc[g]: this lane's group centres (midpoints computed by the kinematics loop).
 template <class T>
-LG_DEV bool self_collide(const KArgs &A, const float *tab, int ln, const float (&root)[13], const V3 (&db)[T::L], AI (&I0)[T::L], S6 (&p0)[T::L], SelfLds<T> &sc) {
+LG_DEV bool self_collide(const KArgs &A, const float *tab, int ln, const float (&root)[13], const V3 (&db)[T::L], const V3 (&gc)[T::NGRP],
+                         AI (&I0)[T::L], S6 (&p0)[T::L], SelfLds<T> &sc) {
     constexpr int K = T::K, L = T::L, NCAP = T::NCAP, NGRP = T::NGRP;
     static_assert(K * NGRP * NGRP <= 32, "candidate bit mask");
     const lg_params &P = A.P;
     const float dt = P.sim_dt, kn = P.contact_stiffness * dt + P.contact_damping, margin = P.contact_margin;
-    __builtin_amdgcn_wave_barrier();                                   // the kinematics loop's LDS writes precede these reads (one wave, in order)
-    V3 gc[NGRP]; float gr[NGRP];
+    float gr[NGRP];
 #pragma unroll
     for (int g = 0; g < NGRP; g++) {
-        gc[g] = (xyz(sc.pos[T::grp_c0(g)][ln]) + xyz(sc.pos[T::grp_c1(g)][ln])) * 0.5f;
         gr[g] = tab[Tab<T>::GRP + g];
         sc.grp[g][ln] = make_float4(gc[g].x, gc[g].y, gc[g].z, gr[g]);
     }
     // base capsules (points come in equal-radius pairs; checked at lg_create), world axes about the base origin
     const M3 R0 = quat_to_mat(root + 3);
-    const V3 w0 = v3(root[10], root[11], root[12]), v0 = v3(root[7], root[8], root[9]);
     const int nbc = (A.base.num_pts + 1) >> 1;
-    CapD bc[2];
-#pragma unroll
-    for (int c = 0; c < 2; c++) {
-        const int i0 = min(2 * c, LG_MAX_BASE_POINTS - 1), i1 = (2 * c + 1 < A.base.num_pts) ? 2 * c + 1 : i0;
-        bc[c].a0 = mul(R0, v3(A.base.pts[i0][0], A.base.pts[i0][1], A.base.pts[i0][2]));
-        bc[c].a1 = mul(R0, v3(A.base.pts[i1][0], A.base.pts[i1][1], A.base.pts[i1][2]));
-        bc[c].v0 = v0 + cross(w0, bc[c].a0); bc[c].v1 = v0 + cross(w0, bc[c].a1); bc[c].rad = A.base.pts[i0][3];
-    }
+    auto base_end = [&](int c, int e) {            // end point e of base capsule c (c < nbc)
+        const int i0 = 2 * c, i = (e && i0 + 1 < A.base.num_pts) ? i0 + 1 : i0;
+        return mul(R0, v3(A.base.pts[i][0], A.base.pts[i][1], A.base.pts[i][2]));
+    };
     // ---- stage 1: which (partner, my group, their group) bounding spheres touch?  bit ((m * NGRP + ga) * NGRP + gb), m = 0: base
     unsigned cand = 0;
+#pragma unroll 1
+    for (int c = 0; c < nbc; c++) {
+        const V3 e0 = base_end(c, 0), d = base_end(c, 1) - e0;
+        const float dd = dot(d, d), rdd = dd > 0.0f ? 1.0f / dd : 0.0f, rb = A.base.pts[2 * c][3];
 #pragma unroll
-    for (int ga = 0; ga < NGRP; ga++) {
-#pragma unroll
-        for (int c = 0; c < 2; c++) {
-            V3 d = bc[c].a1 - bc[c].a0, rel = gc[ga] - bc[c].a0;
-            float dd = dot(d, d), t = dd > 0.0f ? fminf(fmaxf(dot(rel, d) / dd, 0.0f), 1.0f) : 0.0f;
-            V3 off = rel - d * t;
-            float lim = gr[ga] + bc[c].rad + margin;
-            if (c < nbc && dot(off, off) < lim * lim) cand |= 1u << (ga * NGRP);
+        for (int ga = 0; ga < NGRP; ga++) {
+            V3 rel = gc[ga] - e0;
+            V3 off = rel - d * fminf(fmaxf(dot(rel, d) * rdd, 0.0f), 1.0f);
+            float lim = gr[ga] + rb + margin;
+            if (dot(off, off) < lim * lim) cand |= 1u << (ga * NGRP);
         }
     }
-    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_wave_barrier();               // LDS traffic between the lanes of one wave: in order, no s_barrier
 #pragma unroll
     for (int m = 1; m < K; m++) {
 #pragma unroll
@@ -369,39 +366,67 @@ LG_DEV bool self_collide(const KArgs &A, const float *tab, int ln, const float (
         }
     }
     if (__builtin_amdgcn_ballot_w64(cand != 0) == 0) return false;
-    // ---- stage 2 (rare): narrow phase, limb side folded into the body's rigid terms, deepest base contact kept for the passes
+    // ---- stage 2 (only waves with a candidate): narrow phase; the limb side is folded into the body's rigid terms, the deepest
+    // base contact is kept for the passes.  Loops are rolled and every trip / pair is skipped wave-uniformly unless flagged.
 #pragma unroll
     for (int c = 0; c <= NCAP; c++) sc.frc[c][ln] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     float best = -1e30f, best_f0 = 0.0f; V3 best_cxn = v3(0, 0, 0), best_n = v3(0, 0, 0);
+    const V3 w0 = v3(root[10], root[11], root[12]), v0 = v3(root[7], root[8], root[9]);
+    auto apply = [&](int i, const SelfHit &h) {    // limb side of a contact on capsule i
+        const int jc = T::pt_joint(T::cap_p0(i));
+        V3 rj = db[0];
+#pragma unroll
+        for (int jj = 1; jj < L; jj++) if (jj <= jc) rj = rj + db[jj];
+        const V3 r = h.pa - rj, f = h.n * h.f0, rxn = cross(r, h.n);
+#pragma unroll
+        for (int jj = 0; jj < L; jj++) if (jj == jc) {
+            ai_add_rank1(I0[jj], dt * kn, rxn, h.n);
+            p0[jj].w = p0[jj].w - cross(r, f); p0[jj].v = p0[jj].v - f;
+        }
+        float4 acc = sc.frc[i][ln];
+        sc.frc[i][ln] = make_float4(acc.x + f.x, acc.y + f.y, acc.z + f.z, 0.0f);
+    };
 #pragma unroll 1
     for (int m = 0; m < K; m++) {
-        const int lp = ln ^ m, nother = m == 0 ? nbc : NCAP;
+        const unsigned mbits = ((1u << (NGRP * NGRP)) - 1u) << (m * NGRP * NGRP);
+        if (__builtin_amdgcn_ballot_w64((cand & mbits) != 0) == 0) continue;              // nobody near this partner
+        const int lp = ln ^ m;
 #pragma unroll 1
         for (int i = 0; i < NCAP; i++) {
+            const unsigned ibits = ((1u << NGRP) - 1u) << ((m * NGRP + T::cap_grp(i)) * NGRP);
+            if (__builtin_amdgcn_ballot_w64((cand & ibits) != 0) == 0) continue;
+            const int ip0 = T::cap_p0(i), ip1 = T::cap_p1(i);
+            const float4 pa0 = sc.pos[ip0][ln], pa1 = sc.pos[ip1][ln];
+            const bool sa = ip0 == ip1;
+            const int nother = m == 0 ? nbc : NCAP;
 #pragma unroll 1
             for (int j = 0; j < nother; j++) {
                 const unsigned bit = 1u << ((m * NGRP + T::cap_grp(i)) * NGRP + (m == 0 ? 0 : T::cap_grp(j)));
-                if (__builtin_amdgcn_ballot_w64((cand & bit) != 0) == 0) continue;       // wave-uniform skip
-                const CapD Ac = load_cap<T>(sc, ln, T::cap_p0(i), T::cap_p1(i));
-                CapD Bc;
-                if (m == 0) Bc = j == 0 ? bc[0] : bc[1];
-                else Bc = load_cap<T>(sc, lp, T::cap_p0(j), T::cap_p1(j));
-                V3 n, pa, pb; float depth, f0;
-                if ((cand & bit) && capsule_contact(P, Ac, Bc, kn, n, depth, f0, pa, pb)) {
-                    const int jc = T::pt_joint(T::cap_p0(i));
-                    V3 rj = db[0];
-#pragma unroll
-                    for (int jj = 1; jj < L; jj++) if (jj <= jc) rj = rj + db[jj];
-                    const V3 r = pa - rj, f = n * f0, rxn = cross(r, n);
-#pragma unroll
-                    for (int jj = 0; jj < L; jj++) if (jj == jc) {
-                        ai_add_rank1(I0[jj], dt * kn, rxn, n);
-                        p0[jj].w = p0[jj].w - cross(r, f); p0[jj].v = p0[jj].v - f;
+                if (__builtin_amdgcn_ballot_w64((cand & bit) != 0) == 0) continue;
+                SelfHit h; bool hit = false;
+                if (m == 0) {
+                    const V3 e0 = base_end(j, 0), e1 = base_end(j, 1);
+                    auto vel = [&](V3 &va0, V3 &va1, V3 &vb0, V3 &vb1) {
+                        va0 = xyz(sc.vel[ip0][ln]); va1 = xyz(sc.vel[ip1][ln]); vb0 = v0 + cross(w0, e0); vb1 = v0 + cross(w0, e1);
+                    };
+                    if (cand & bit) hit = sa ? capsule_contact<true, false>(P, kn, xyz(pa0), xyz(pa1), pa0.w, e0, e1, A.base.pts[2 * j][3], vel, h)
+                                             : capsule_contact<false, false>(P, kn, xyz(pa0), xyz(pa1), pa0.w, e0, e1, A.base.pts[2 * j][3], vel, h);
+                    if (hit && h.depth > best) { best = h.depth; best_f0 = h.f0; best_n = h.n; best_cxn = cross(h.pb, h.n); }
+                } else {
+                    const int jp0 = T::cap_p0(j), jp1 = T::cap_p1(j);
+                    const float4 pb0 = sc.pos[jp0][lp], pb1 = sc.pos[jp1][lp];
+                    const bool sb = jp0 == jp1;
+                    auto vel = [&](V3 &va0, V3 &va1, V3 &vb0, V3 &vb1) {
+                        va0 = xyz(sc.vel[ip0][ln]); va1 = xyz(sc.vel[ip1][ln]); vb0 = xyz(sc.vel[jp0][lp]); vb1 = xyz(sc.vel[jp1][lp]);
+                    };
+                    if (cand & bit) {              // the shape kinds are wave-uniform (i, j are loop counters): no divergence from the dispatch
+                        if (sa && sb) hit = capsule_contact<true, true>(P, kn, xyz(pa0), xyz(pa1), pa0.w, xyz(pb0), xyz(pb1), pb0.w, vel, h);
+                        else if (sa) hit = capsule_contact<true, false>(P, kn, xyz(pa0), xyz(pa1), pa0.w, xyz(pb0), xyz(pb1), pb0.w, vel, h);
+                        else if (sb) hit = capsule_contact<false, true>(P, kn, xyz(pa0), xyz(pa1), pa0.w, xyz(pb0), xyz(pb1), pb0.w, vel, h);
+                        else hit = capsule_contact<false, false>(P, kn, xyz(pa0), xyz(pa1), pa0.w, xyz(pb0), xyz(pb1), pb0.w, vel, h);
                     }
-                    float4 acc = sc.frc[i][ln];
-                    sc.frc[i][ln] = make_float4(acc.x + f.x, acc.y + f.y, acc.z + f.z, 0.0f);
-                    if (m == 0 && depth > best) { best = depth; best_f0 = f0; best_n = n; best_cxn = cross(pb, n); }
                 }
+                if (__builtin_amdgcn_ballot_w64(hit) != 0) { if (hit) apply(i, h); }
             }
         }
     }
@@ -440,6 +465,7 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, int lane_k, float 
     S6 p0[L], p0b;
     Contact cb, cl[NPT];
     HfFetch fb, fl[NPT];               // ground samples of all collision points: fetched here, evaluated after the loop
+    V3 sgc[T::NGRP];          // self-collision: bounding-sphere centre of each point group (midpoint of its two anchor points)
     {
         float sc = base_mass / A.base.mass, Il[6];
 #pragma unroll
@@ -500,6 +526,11 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, int lane_k, float 
                     const int ln = threadIdx.x % LG_BLOCK;
                     sc->pos[i][ln] = make_float4(pw.x, pw.y, pw.z, tp[3]);
                     sc->vel[i][ln] = make_float4(cl[i].vc.x, cl[i].vc.y, cl[i].vc.z, 0.0f);
+#pragma unroll
+                    for (int g = 0; g < T::NGRP; g++) {
+                        if (T::grp_c0(g) == i) sgc[g] = pw;
+                        if (T::grp_c1(g) == i) sgc[g] = (sgc[g] + pw) * 0.5f;
+                    }
                 }
             }
             Rpar = Rj; rpar = rj; wpar = wj; vpar = vj;
@@ -525,7 +556,7 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, int lane_k, float 
         for (int j = 0; j < L; j++) bt_load(bt[j], threadIdx.x % LG_BLOCK, I0[j], p0[j]);
     }
     bool any_self = false;                                 // wave-uniform
-    if (SC) any_self = self_collide<T>(A, tab, threadIdx.x % LG_BLOCK, root, db, I0, p0, *sc);
+    if constexpr (SC) any_self = self_collide<T>(A, tab, threadIdx.x % LG_BLOCK, root, db, sgc, I0, p0, *sc);
     LG_PROF(PF_TORQUE);
     // ---- articulated-body passes with the contact impedances folded in
     S6 U[L], acc0;
