@@ -57,9 +57,10 @@ template <class T> struct Tab { static constexpr int GRP = T::L * LG_JS + 4 * T:
                           static constexpr int STRIDE = GRP + T::NGRP + 1; };
 // per-joint offsets inside the limb table
 enum { J_POS = 0, J_ROT = 3, J_AXIS = 12, J_MASS = 15, J_COM = 16, J_INERTIA = 19, J_LO = 25, J_HI = 26, J_VLIM = 27,
-       J_ARM = 28, J_DAMP = 29, J_KP = 30, J_KD = 31, J_Q0 = 32, J_TLIM = 33, J_SLO = 34, J_SHI = 35, J_DVL = 36 };
+       J_ARM = 28, J_DAMP = 29, J_KP = 30, J_KD = 31, J_Q0 = 32, J_TLIM = 33, J_SLO = 34, J_SHI = 35, J_DVL = 36,
+       J_SUBM = 37 /* mass of the limb from this joint outwards (self-collision weights) */ };
 
-struct BaseTab { float mass, com[3], inertia[6]; float pts[LG_MAX_BASE_POINTS][4]; int32_t num_pts; };   // num_pts <= K
+struct BaseTab { float mass, com[3], inertia[6]; float pts[LG_MAX_BASE_POINTS][4]; int32_t num_pts; float mass_robot; };   // num_pts <= K; mass_robot: nominal total mass
 
 struct KArgs {                 // passed by value: lives in the kernarg segment -> scalar loads
     lg_params  P;
@@ -296,6 +297,7 @@ template <bool SA, bool SB> LG_DEV void seg_seg_closest(V3 a0, V3 a1, V3 b0, V3 
     }
 }
 struct SelfHit { V3 n, pa, pb; float depth, f0; };
+// (mass-ratio weighted block Jacobi: see the oracle's "self-collision" comment)
 // One capsule pair: A = segment a0-a1 (radius ra) of this lane's limb, B = the other shape.  Geometry first; the velocities
 // (`vel`: callback returning the four end-point velocities) are only fetched for pairs within the contact margin.
 template <bool SA, bool SB, class Vel>
@@ -311,8 +313,8 @@ LG_DEV bool capsule_contact(const lg_params &P, float kn, V3 a0, V3 a1, float ra
     h.n = diff * (1.0f / fmaxf(dist, 1e-9f));
     V3 va = va0 + (va1 - va0) * s, vb = vb0 + (vb1 - vb0) * t;
     float f = P.contact_stiffness * d - kn * dot(h.n, va - vb);
-    if (!(f > 0.0f)) return false;
-    h.depth = d; h.f0 = f; h.pa = ca - h.n * ra; h.pb = cb + h.n * rb;
+    if (!(d > 0.0f || f > 0.0f)) return false;       // speculative range: only when approaching; overlapping shapes stay coupled (oracle comment)
+    h.depth = d; h.f0 = fmaxf(f, 0.0f); h.pa = ca - h.n * ra; h.pb = cb + h.n * rb;
     return true;
 }
 // Returns (wave-uniform) whether any lane of the wave went through the narrow phase: only then do sc.base / sc.frc hold data.
@@ -372,20 +374,25 @@ LG_DEV bool self_collide(const KArgs &A, const float *tab, int ln, const float (
     for (int c = 0; c <= NCAP; c++) sc.frc[c][ln] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     float best = -1e30f, best_f0 = 0.0f; V3 best_cxn = v3(0, 0, 0), best_n = v3(0, 0, 0);
     const V3 w0 = v3(root[10], root[11], root[12]), v0 = v3(root[7], root[8], root[9]);
-    auto apply = [&](int i, const SelfHit &h) {    // limb side of a contact on capsule i
+    // limb side of a contact on capsule i against a shape backed by mass mB; returns the force estimate that is exported
+    auto apply = [&](int i, const SelfHit &h, float mB) {
         const int jc = T::pt_joint(T::cap_p0(i));
+        const float mA = tab[jc * LG_JS + J_SUBM];
         V3 rj = db[0];
 #pragma unroll
         for (int jj = 1; jj < L; jj++) if (jj <= jc) rj = rj + db[jj];
         const V3 r = h.pa - rj, f = h.n * h.f0, rxn = cross(r, h.n);
 #pragma unroll
         for (int jj = 0; jj < L; jj++) if (jj == jc) {
-            ai_add_rank1(I0[jj], dt * kn, rxn, h.n);
+            ai_add_rank1(I0[jj], dt * kn * (1.0f + mA / mB), rxn, h.n);
             p0[jj].w = p0[jj].w - cross(r, f); p0[jj].v = p0[jj].v - f;
         }
+        const float frep = h.f0 / (1.0f + kn * dt * (1.0f / mA + 1.0f / mB));
         float4 acc = sc.frc[i][ln];
-        sc.frc[i][ln] = make_float4(acc.x + f.x, acc.y + f.y, acc.z + f.z, 0.0f);
+        sc.frc[i][ln] = make_float4(acc.x + h.n.x * frep, acc.y + h.n.y * frep, acc.z + h.n.z * frep, 0.0f);
+        return frep;
     };
+    float best_coef = 0.0f, best_frep = 0.0f;
 #pragma unroll 1
     for (int m = 0; m < K; m++) {
         const unsigned mbits = ((1u << (NGRP * NGRP)) - 1u) << (m * NGRP * NGRP);
@@ -411,7 +418,6 @@ LG_DEV bool self_collide(const KArgs &A, const float *tab, int ln, const float (
                     };
                     if (cand & bit) hit = sa ? capsule_contact<true, false>(P, kn, xyz(pa0), xyz(pa1), pa0.w, e0, e1, A.base.pts[2 * j][3], vel, h)
                                              : capsule_contact<false, false>(P, kn, xyz(pa0), xyz(pa1), pa0.w, e0, e1, A.base.pts[2 * j][3], vel, h);
-                    if (hit && h.depth > best) { best = h.depth; best_f0 = h.f0; best_n = h.n; best_cxn = cross(h.pb, h.n); }
                 } else {
                     const int jp0 = T::cap_p0(j), jp1 = T::cap_p1(j);
                     const float4 pb0 = sc.pos[jp0][lp], pb1 = sc.pos[jp1][lp];
@@ -426,13 +432,22 @@ LG_DEV bool self_collide(const KArgs &A, const float *tab, int ln, const float (
                         else hit = capsule_contact<false, false>(P, kn, xyz(pa0), xyz(pa1), pa0.w, xyz(pb0), xyz(pb1), pb0.w, vel, h);
                     }
                 }
-                if (__builtin_amdgcn_ballot_w64(hit) != 0) { if (hit) apply(i, h); }
+                if (__builtin_amdgcn_ballot_w64(hit) != 0) {
+                    if (hit) {
+                        const float mB = m == 0 ? A.base.mass_robot : (tab + ((lp & (K - 1)) - (ln & (K - 1))) * Tab<T>::STRIDE)[T::pt_joint(T::cap_p0(m == 0 ? 0 : j)) * LG_JS + J_SUBM];
+                        const float frep = apply(i, h, mB);
+                        if (m == 0 && h.depth > best) {
+                            best = h.depth; best_f0 = h.f0; best_n = h.n; best_cxn = cross(h.pb, h.n); best_frep = frep;
+                            best_coef = dt * kn * (1.0f + mB / tab[T::pt_joint(T::cap_p0(i)) * LG_JS + J_SUBM]);
+                        }
+                    }
+                }
             }
         }
     }
-    sc.base[0][ln] = make_float4(best_cxn.x, best_cxn.y, best_cxn.z, best);
+    sc.base[0][ln] = make_float4(best_cxn.x, best_cxn.y, best_cxn.z, best > -1e29f ? best_coef : -1.0f);   // w: implicit coefficient, < 0: none
     sc.base[1][ln] = make_float4(best_n.x, best_n.y, best_n.z, best_f0);
-    if (best > -1e29f) sc.frc[NCAP][ln] = make_float4(-best_n.x * best_f0, -best_n.y * best_f0, -best_n.z * best_f0, 0.0f);
+    if (best > -1e29f) sc.frc[NCAP][ln] = make_float4(-best_n.x * best_frep, -best_n.y * best_frep, -best_n.z * best_frep, 0.0f);
     return true;
 }
 
@@ -603,8 +618,8 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, int lane_k, float 
         contact_assemble(cb, P, kn, Ia, pa);      // this lane's base point (about the base origin, like Ia after the shift)
         if (SC && any_self) {                     // reaction of this limb's deepest base contact: force -n f0 on the base, implicit in the base's motion
             const float4 s0 = sc->base[0][threadIdx.x % LG_BLOCK], s1 = sc->base[1][threadIdx.x % LG_BLOCK];
-            if (s0.w > -1e29f) {
-                ai_add_rank1(Ia, dt * kn, xyz(s0), xyz(s1));
+            if (s0.w >= 0.0f) {
+                ai_add_rank1(Ia, s0.w, xyz(s0), xyz(s1));
                 pa.w = pa.w + xyz(s0) * s1.w; pa.v = pa.v + xyz(s1) * s1.w;
             }
         }
@@ -1604,6 +1619,9 @@ template <class T> static void fill_limb_table(const lg_params &P, const lg_robo
             tj[J_ARM] = M.dof_armature[d]; tj[J_DAMP] = M.dof_damping[d];
             tj[J_KP] = P.p_gains[d]; tj[J_KD] = P.d_gains[d]; tj[J_Q0] = P.default_dof_pos[d]; tj[J_TLIM] = P.torque_limits[d];
             tj[J_SLO] = P.soft_pos_lower[d]; tj[J_SHI] = P.soft_pos_upper[d]; tj[J_DVL] = P.dof_vel_limits[d];
+            float sub = 0.0f;
+            for (int jj = j; jj < T::L; jj++) sub += M.body_mass[k * T::L + jj];
+            tj[J_SUBM] = sub;
         }
         for (int i = 0; i < T::NPT; i++) {
             float *tp = tk + T::L * LG_JS + 4 * i;
@@ -1680,6 +1698,8 @@ static int upload_tables(lg_sim *s) {
     memcpy(s->base.com, s->M.base_com, 12); memcpy(s->base.inertia, s->M.base_inertia, 24);
     memset(s->base.pts, 0, sizeof s->base.pts);
     s->base.num_pts = s->M.num_base_points;
+    s->base.mass_robot = s->M.base_mass;
+    for (int d = 0; d < s->M.num_limbs * s->M.chain_len; d++) s->base.mass_robot += s->M.body_mass[d];
     for (int i = 0; i < s->M.num_base_points; i++) { memcpy(s->base.pts[i], s->M.base_points[i].pos, 12); s->base.pts[i][3] = s->M.base_points[i].radius; }
     return 0;
 }

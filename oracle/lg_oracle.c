@@ -285,13 +285,21 @@ static inline float motor_torque(float tau, float qd, float vlim) {
  *     point is a sphere (ANYmal-C limb: KFE-drive capsule on the THIGH, shank capsule, foot sphere; base capsule);
  *   - pairs: every limb capsule against the base capsules and against the capsules of every OTHER limb (links of one limb
  *     are adjacent or out of each other's reach); closest points of the two segments, depth = ra + rb - distance;
- *   - force: frictionless implicit spring-damper along the contact normal, f = max(0, K d - kappa v_n) with v_n the relative
- *     normal velocity at the start of the sub-step; active for d > -contact_margin and f > 0;
- *   - coupling: each body treats the other as moving with its start-of-step velocity (block Jacobi): the limb body gets
- *     dt kappa g g^T added to its rigid-body inertia and -J^T f to its bias force before the articulated-body passes; the
- *     base gets the reaction of each limb's DEEPEST base contact the same way (it rides with that limb's partial sums);
- *   - contact_forces: the exported net contact force of a body includes its self-collision forces (as PhysX's does). */
-typedef struct { v3 a0, a1, va0, va1; float rad; int body, report; } capsule_t;
+ *   - force: frictionless implicit spring-damper along the contact normal, bias s = max(0, K d - kappa v_n) with v_n the relative
+ *     normal velocity at the start of the sub-step; active while the shapes overlap (d > 0), and in the speculative range
+ *     -contact_margin < d <= 0 when K d - kappa v_n > 0 (approaching fast enough to touch within the step);
+ *   - coupling: block Jacobi with mass-ratio weights.  The true contact force is implicit in the RELATIVE acceleration,
+ *     f = s - kappa dt n.(a_A - a_B) with s = K d - kappa v_n; each body only knows its own acceleration, so body A uses
+ *     f = s - kappa (1 + mA/mB) dt n.a_A and body B the mirror image (mA, mB: nominal masses behind the two shapes -- the
+ *     limb sub-tree from the carrying joint outwards, the whole robot for the base).  For a single contact this reproduces the
+ *     coupled solution exactly when the ratio is right, and for ANY positive ratio the two velocity corrections add up to
+ *     exactly the relative normal velocity (no overshoot: plain Jacobi, ratio term dropped, makes stiff contacts swap the two
+ *     bodies' velocities every sub-step).  The limb body gets dt kappa (1 + mA/mB) g g^T added to its rigid-body inertia and
+ *     -J^T s to its bias force before the articulated-body passes; the base gets the reaction of each limb's DEEPEST base
+ *     contact the same way (it rides with that limb's partial sums);
+ *   - contact_forces: the exported net contact force of a body includes its self-collision forces (as PhysX's does), estimated
+ *     as s / (1 + kappa dt (1/mA + 1/mB)) along the normal -- equal and opposite on the two bodies. */
+typedef struct { v3 a0, a1, va0, va1; float rad, mhat; int body, report; } capsule_t;
 
 static void seg_seg_closest(v3 a0, v3 a1, v3 b0, v3 b1, float *ps, float *pt) {
     /* closest points a0 + s (a1 - a0), b0 + t (b1 - b0), s, t in [0,1] (Ericson, Real-Time Collision Detection 5.1.9) */
@@ -330,12 +338,15 @@ static int build_capsules(const lg_robot_model *M, int g, int L, const float (*R
         c->a0 = add(rb[b], r0); c->a1 = add(rb[b], r1);
         c->va0 = add(vb[b], cross(wb[b], r0)); c->va1 = add(vb[b], cross(wb[b], r1));
         c->rad = p0->radius; c->body = b; c->report = p0->report_body;
+        c->mhat = 0.0f;                                   /* nominal mass behind the shape */
+        if (g < 0) { c->mhat = M->base_mass; for (int d = 0; d < M->num_limbs * L; d++) c->mhat += M->body_mass[d]; }
+        else for (int jj = p0->joint; jj < L; jj++) c->mhat += M->body_mass[g * L + jj];
         i = j + 1;
     }
     return n;
 }
 
-typedef struct { int on; float depth, f0; v3 cxn, n; } base_slot_t;     /* reaction of a limb's deepest base contact */
+typedef struct { int on; float depth, f0, coef, frep; v3 cxn, n; } base_slot_t;     /* reaction of a limb's deepest base contact */
 
 /* one capsule pair: A (on a limb body) against B.  Returns 1 and fills (n: from B to A, depth, f0, contact points) when active. */
 static int capsule_contact(const lg_params *P, const capsule_t *A, const capsule_t *B, float kn, v3 *n, float *depth, float *f0, v3 *pa, v3 *pb) {
@@ -350,8 +361,11 @@ static int capsule_contact(const lg_params *P, const capsule_t *A, const capsule
     v3 va = add(A->va0, scl(sub(A->va1, A->va0), s)), vbv = add(B->va0, scl(sub(B->va1, B->va0), t));
     float vn = dot(*n, sub(va, vbv));
     float f = P->contact_stiffness * d - kn * vn;
-    if (!(f > 0.0f)) return 0;
-    *depth = d; *f0 = f;
+    /* speculative range (not yet touching): only when approaching fast enough to touch within the step.  Overlapping shapes
+     * stay coupled even while they separate (s <= 0 -> no bias force, the implicit term alone): a contact that switched off
+     * there would alternate on / off from sub-step to sub-step and let the actuators push the links back in on the off beats */
+    if (!(d > 0.0f || f > 0.0f)) return 0;
+    *depth = d; *f0 = fmaxf(f, 0.0f);
     *pa = sub(ca, scl(*n, A->rad));              /* contact point on A's surface */
     *pb = add(cb, scl(*n, B->rad));              /* ... on B's surface */
     return 1;
@@ -484,18 +498,21 @@ static void physics_substep_env(const lgo_sim *s, int e, const float *tau, int w
                     const capsule_t *A = &climb[k][i];
                     v3 n, pa, pb; float depth, f0;
                     if (!capsule_contact(P, A, &other[j], kn_s, &n, &depth, &f0, &pa, &pb)) continue;
+                    const float mA = A->mhat, mB = other[j].mhat;
                     v3 r = sub(pa, rb[A->body]);                          /* arm about the body's own joint origin */
-                    ai_add_rank1(&I0[A->body], dt * kn_s, cross(r, n), n);
+                    ai_add_rank1(&I0[A->body], dt * kn_s * (1.0f + mA / mB), cross(r, n), n);
                     v3 f = scl(n, f0);
                     p0[A->body].w = sub(p0[A->body].w, cross(r, f));
                     p0[A->body].v = sub(p0[A->body].v, f);
-                    self_cf[A->report][0] += f.x; self_cf[A->report][1] += f.y; self_cf[A->report][2] += f.z;
+                    float frep = f0 / (1.0f + kn_s * dt * (1.0f / mA + 1.0f / mB));
+                    self_cf[A->report][0] += n.x * frep; self_cf[A->report][1] += n.y * frep; self_cf[A->report][2] += n.z * frep;
                     if (m == 0 && (!bslot[k].on || depth > bslot[k].depth)) {
                         bslot[k].on = 1; bslot[k].depth = depth; bslot[k].f0 = f0; bslot[k].n = n; bslot[k].cxn = cross(pb, n);
+                        bslot[k].coef = dt * kn_s * (1.0f + mB / mA); bslot[k].frep = frep;
                     }
                 }
             }
-            if (bslot[k].on) { self_cf[0][0] -= bslot[k].n.x * bslot[k].f0; self_cf[0][1] -= bslot[k].n.y * bslot[k].f0; self_cf[0][2] -= bslot[k].n.z * bslot[k].f0; }
+            if (bslot[k].on) { self_cf[0][0] -= bslot[k].n.x * bslot[k].frep; self_cf[0][1] -= bslot[k].n.y * bslot[k].frep; self_cf[0][2] -= bslot[k].n.z * bslot[k].frep; }
         }
     }
 
@@ -558,8 +575,7 @@ static void physics_substep_env(const lgo_sim *s, int e, const float *tau, int w
             pt_->v = sub(pt_->v, f);
         }
         for (int k = 0; k < K; k++) if (bslot[k].on) {      /* reaction of limb k's deepest base contact: force -n f on the base */
-            const float kn_s = P->contact_stiffness * dt + P->contact_damping;
-            ai_add_rank1(&IBp[k], dt * kn_s, bslot[k].cxn, bslot[k].n);
+            ai_add_rank1(&IBp[k], bslot[k].coef, bslot[k].cxn, bslot[k].n);
             pBp[k].w = add(pBp[k].w, scl(bslot[k].cxn, bslot[k].f0));
             pBp[k].v = add(pBp[k].v, scl(bslot[k].n, bslot[k].f0));
         }

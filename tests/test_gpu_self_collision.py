@@ -37,18 +37,7 @@ def _get(d, name):
     return (t.to(torch.uint8) if t.dtype == torch.bool else t).cpu().numpy()
 
 
-def _adversarial_actions(robot, p, N, seed=0):
-    """All four HAA joints swing towards the body's mid-plane, the knees fold: legs are driven into each other and into the trunk."""
-    q0 = np.array(list(p.default_dof_pos)[:12], np.float64)
-    _, sign, (lf, rf) = _crossing_pose(robot, q0)
-    rng = np.random.default_rng(seed)
-    act = np.zeros((N, 12), np.float32)
-    for d, nme in enumerate(robot.dof_names):
-        if nme.endswith("HAA"):
-            act[:, d] = (sign[lf] if nme.startswith("L") else sign[rf]) * rng.uniform(1.5, 3.0, N)
-        if nme.endswith("KFE"):
-            act[:, d] = np.sign(q0[d]) * rng.uniform(1.0, 3.0, N)
-    return act
+from tests.test_oracle_physics import adversarial_actions as _adversarial_actions  # noqa: E402
 
 
 @pytest.mark.parametrize("task", ["anymal_c_flat", "a1"])
@@ -138,10 +127,14 @@ def test_policy_step_parity_with_self_collision():
 
 @pytest.mark.parametrize("N", [4096])
 def test_no_interpenetration_under_adversarial_actions_full_size(N):
-    """BASELINE.json configs[1] size.  50 policy steps of adversarial actions: with self-collision (the flat config's setting) no
-    capsule pair of any env overlaps by more than contact_offset = 1 cm; the same run without it interpenetrates by centimetres."""
+    """BASELINE.json configs[1] size; same protocol as the oracle's test (tests/test_oracle_physics.py): 50 policy steps of
+    saturating inward targets (legs thrash into each other at up to the 20 rad/s joint speed limit), then 30 steps of the same
+    targets scaled down (pressed together, quasi-static).  With self-collision (the flat config's setting) overlaps beyond
+    contact_offset = 1 cm are rare and below 3 cm while thrashing, and millimetres once static; without it the legs sit ~10 cm
+    inside each other."""
     from legged_games_gym_amd.device_sim import DeviceSim
-    worst = {}
+    res = {}
+    sample = np.arange(0, N, 16)                                  # 256 envs per checkpoint (float64 brute-force capsule distances)
     for on in (True, False):
         cfg, robot, p, names, model, w = make_setup("anymal_c_flat", N, tweak=lambda c: setattr(c.asset, "self_collisions", 0 if on else 1))
         d = DeviceSim(p, model, robot, torch.device("cuda:0"), w)
@@ -150,17 +143,17 @@ def test_no_interpenetration_under_adversarial_actions_full_size(N):
         d.buf["friction_coeffs"].copy_(torch.from_numpy(fr)); d.buf["base_mass_delta"].copy_(torch.from_numpy(dm))
         d.reset_idx(torch.arange(N, dtype=torch.int32), 0)
         act = torch.from_numpy(_adversarial_actions(robot, p, N, seed=1)).cuda()
-        mins = []
-        for it in range(1, 51):
-            d.step(act, it)
-            if it in (10, 20, 30, 40, 50):
+        clear = []
+        for it in range(1, 81):
+            d.step(act if it <= 50 else 0.35 * act, it)
+            if it in (10, 20, 30, 40, 50, 76, 80):
                 q = _get(d, "dof_state").reshape(N, 12, 2)[..., 0].astype(np.float64)
-                sample = np.arange(0, N, 16)                       # 256 envs per checkpoint (float64 brute-force capsule distances)
-                mins.append(min(min_self_clearance(robot, q[e], samples=17) for e in sample))
+                clear.append([min_self_clearance(robot, q[e], samples=17) for e in sample])
         assert np.isfinite(_get(d, "root_states")).all() and np.isfinite(_get(d, "obs_buf")).all()
-        worst[on] = mins
-        print("min clearance at steps 10..50, self-collision", "on:" if on else "off:", np.round(mins, 4))
-    assert min(worst[False]) < -0.03, worst
-    # settled (step 50): within contact_offset (+ fp / sampling slack).  On the way there legs that slam together at several m/s
-    # travel more than the 1 cm contact margin in one 5 ms sub-step before the contact engages: transient overlap stays below 3 cm
-    assert worst[True][-1] > -(0.01 + 0.004) and min(worst[True]) > -0.03, worst
+        res[on] = np.array(clear)
+        print("self-collision", "on: " if on else "off:", "min clearance per checkpoint", np.round(res[on].min(axis=1), 4),
+              "share of envs beyond contact_offset", np.round((res[on] < -0.01).mean(axis=1), 3))
+    thrash_on, thrash_off = res[True][:5], res[False][:5]
+    assert thrash_off.min() < -0.05 and (thrash_off < -0.01).mean() > 0.25
+    assert thrash_on.min() > -0.03 and (thrash_on < -0.01).mean() < 0.05, (thrash_on.min(), (thrash_on < -0.01).mean())
+    assert res[True][-2:].min() > -0.005 and res[False][-2:].min() < -0.02, (res[True][-2:].min(), res[False][-2:].min())
