@@ -25,6 +25,7 @@ using namespace lg;
 #define LG_BLOCK 64            // (env, limb) lanes per workgroup = one wave; 4096 envs x 4 limbs = 256 workgroups = one per CU
 #define LG_JS 40               // floats per joint in the LDS limb table
 #define LG_PASSES 2
+#define LG_STEP_WAVES 4          // waves per workgroup of the fused step: 1 rigid-body wave + 3 helpers
 
 // ------------------------------------------------------------------ robot topologies compiled in
 struct AnymalTraits {          // quadruped (ANYmal-C/B, A1): base + 4 legs x 3 joints; points: 2 thigh, 2 shank, foot sphere
@@ -40,6 +41,8 @@ struct AnymalTraits {          // quadruped (ANYmal-C/B, A1): base + 4 legs x 3 
     static constexpr int cap_grp(int c) { return c == 0 ? 0 : 1; }
     static constexpr int grp_c0(int g) { return g == 0 ? 0 : 2; }       // group centre = midpoint of these two points
     static constexpr int grp_c1(int g) { return g == 0 ? 1 : 4; }
+    static constexpr int grp_cap_lo(int g) { return g == 0 ? 0 : 1; }   // capsules [lo, hi) of the group (= of one body)
+    static constexpr int grp_cap_hi(int g) { return g == 0 ? 1 : 3; }
 };
 struct CassieTraits {          // pelvis + 2 legs x 6 joints; points: toe capsule
     static constexpr int K = 2, L = 6, NREP = 6, NPT = 2;
@@ -52,6 +55,8 @@ struct CassieTraits {          // pelvis + 2 legs x 6 joints; points: toe capsul
     static constexpr int cap_grp(int) { return 0; }
     static constexpr int grp_c0(int) { return 0; }
     static constexpr int grp_c1(int) { return 1; }
+    static constexpr int grp_cap_lo(int) { return 0; }
+    static constexpr int grp_cap_hi(int) { return 1; }
 };
 template <class T> struct Tab { static constexpr int GRP = T::L * LG_JS + 4 * T::NPT;                 // bounding radius of each point group
                           static constexpr int STRIDE = GRP + T::NGRP + 1; };
@@ -265,16 +270,22 @@ LG_DEV void bt_load(const float4 (*src)[LG_BLOCK], int lane, AI &I, S6 &p) {
 
 // ------------------------------------------------------------------ self-collision (asset.self_collisions = 0; DESIGN.md "Self-collision")
 // Twin of oracle/lg_oracle.c "self-collision": limb capsules against the base capsules and against the capsules of the other
-// limbs; frictionless implicit spring-dampers, block-Jacobi between the two bodies.  Lane (env, limb k) owns limb k's side of
-// every pair and the base reaction of its deepest base contact.  Collision spheres travel between the K lanes of an env
-// through LDS (same wave: no barrier); group bounding spheres cull, and every narrow-phase pair test is skipped wave-uniformly
-// unless some lane of the wave flagged that group pair.
+// limbs; per limb body and partner the deepest active pair becomes a frictionless implicit spring-damper, coupled by
+// mass-ratio weighted block Jacobi, and enters the LAST articulated-body pass.
+// Division of labour in the four-wave step kernel: the rigid-body wave publishes every collision sphere (position, velocity),
+// the group bounding spheres and the base pose to LDS during its kinematics loop; helper wave w (idle once the sub-step's
+// torques / body terms are handed over) does partner m = w for all 64 (env, limb) lanes -- wave 1 also the base -- while the
+// rigid-body wave runs its first pass, and leaves one record per (partner, body) in LDS; the rigid-body wave folds the
+// records in before its final pass.  Kernels without three helper waves run the same detection on the rigid-body wave.
+// Every narrow-phase pair test is skipped wave-uniformly unless some lane of the wave flagged that pair of bounding spheres.
+#define LG_SC_REC 4                      // float4 per record: (n, f0) (pa, coef) (pb, coef of the other side) (frep, capsule, -, -)
 template <class T> struct SelfLds {
     float4 pos[T::NPT][LG_BLOCK];        // sphere centres relative to the base origin (world axes); w = radius
     float4 vel[T::NPT][LG_BLOCK];        // their velocities
-    float4 grp[T::NGRP][LG_BLOCK];       // bounding sphere of each point group: centre, radius
-    float4 base[2][LG_BLOCK];            // reaction of the lane's deepest base contact: (c x n, depth), (n, f0); depth < -1e29: none
-    float4 frc[T::NCAP + 1][LG_BLOCK];   // self-collision force on each capsule's report body, [NCAP]: this lane's share on the base
+    float4 grp[T::NGRP][LG_BLOCK];       // bounding sphere of each point group (= shapes of one body): centre, radius
+    float4 basepose[5][LG_BLOCK];        // rows of the base rotation, base angular and linear velocity (of the lane's env)
+    float4 rec[T::K][T::NGRP][LG_SC_REC][LG_BLOCK];   // deepest contact of body g of this lane's limb with partner m (0: base; m: limb k ^ m); coef < 0: none
+    int    ready[LG_STEP_WAVES];         // helper wave w: sub-step number once its records are complete
 };
 LG_DEV V3 xyz(float4 a) { return v3(a.x, a.y, a.z); }
 // closest points of two segments, parameters in [0,1] (Ericson, RTCD 5.1.9); SA / SB: that "segment" is a point (compile time)
@@ -297,7 +308,6 @@ template <bool SA, bool SB> LG_DEV void seg_seg_closest(V3 a0, V3 a1, V3 b0, V3 
     }
 }
 struct SelfHit { V3 n, pa, pb; float depth, f0; };
-// (mass-ratio weighted block Jacobi: see the oracle's "self-collision" comment)
 // One capsule pair: A = segment a0-a1 (radius ra) of this lane's limb, B = the other shape.  Geometry first; the velocities
 // (`vel`: callback returning the four end-point velocities) are only fetched for pairs within the contact margin.
 template <bool SA, bool SB, class Vel>
@@ -317,138 +327,141 @@ LG_DEV bool capsule_contact(const lg_params &P, float kn, V3 a0, V3 a1, float ra
     h.depth = d; h.f0 = fmaxf(f, 0.0f); h.pa = ca - h.n * ra; h.pb = cb + h.n * rb;
     return true;
 }
-// Returns (wave-uniform) whether any lane of the wave went through the narrow phase: only then do sc.base / sc.frc hold data.
-// gc[g]: this lane's group centres (midpoints computed by the kinematics loop).
+// Detection for partner m (0: the base) of every lane of the calling wave: records sc.rec[m][*][*][ln].  Reads only LDS
+// (spheres, group bounds, base pose, limb tables) and kernel arguments, so any wave of the workgroup can run it.
 template <class T>
-LG_DEV bool self_collide(const KArgs &A, const float *tab, int ln, const float (&root)[13], const V3 (&db)[T::L], const V3 (&gc)[T::NGRP],
-                         AI (&I0)[T::L], S6 (&p0)[T::L], SelfLds<T> &sc) {
-    constexpr int K = T::K, L = T::L, NCAP = T::NCAP, NGRP = T::NGRP;
-    static_assert(K * NGRP * NGRP <= 32, "candidate bit mask");
+LG_DEV void self_detect(const KArgs &A, const float *lds_tab, int ln, int m, SelfLds<T> &sc) {
+    constexpr int K = T::K, NCAP = T::NCAP, NGRP = T::NGRP;
     const lg_params &P = A.P;
     const float dt = P.sim_dt, kn = P.contact_stiffness * dt + P.contact_damping, margin = P.contact_margin;
-    float gr[NGRP];
-#pragma unroll
-    for (int g = 0; g < NGRP; g++) {
-        gr[g] = tab[Tab<T>::GRP + g];
-        sc.grp[g][ln] = make_float4(gc[g].x, gc[g].y, gc[g].z, gr[g]);
-    }
-    // base capsules (points come in equal-radius pairs; checked at lg_create), world axes about the base origin
-    const M3 R0 = quat_to_mat(root + 3);
+    const int k = ln & (K - 1), lp = ln ^ m;
+    const float *tab = lds_tab + k * Tab<T>::STRIDE, *tabp = lds_tab + (k ^ m) * Tab<T>::STRIDE;
     const int nbc = (A.base.num_pts + 1) >> 1;
-    auto base_end = [&](int c, int e) {            // end point e of base capsule c (c < nbc)
+    // base pose of the lane's env (m == 0 only)
+    M3 R0; V3 w0 = v3(0, 0, 0), v0 = v3(0, 0, 0);
+    if (m == 0) {
+        const float4 a = sc.basepose[0][ln], b = sc.basepose[1][ln], c = sc.basepose[2][ln];
+        R0.m[0] = a.x; R0.m[1] = a.y; R0.m[2] = a.z; R0.m[3] = b.x; R0.m[4] = b.y; R0.m[5] = b.z; R0.m[6] = c.x; R0.m[7] = c.y; R0.m[8] = c.z;
+        w0 = xyz(sc.basepose[3][ln]); v0 = xyz(sc.basepose[4][ln]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 9; i++) R0.m[i] = 0.0f;
+    }
+    auto base_end = [&](int c, int e) {            // end point e of base capsule c (points come in equal-radius pairs; checked at lg_create)
         const int i0 = 2 * c, i = (e && i0 + 1 < A.base.num_pts) ? i0 + 1 : i0;
         return mul(R0, v3(A.base.pts[i][0], A.base.pts[i][1], A.base.pts[i][2]));
     };
-    // ---- stage 1: which (partner, my group, their group) bounding spheres touch?  bit ((m * NGRP + ga) * NGRP + gb), m = 0: base
+    // ---- stage 1: which (my body, their body) bounding spheres touch?  bit ga * NGRP + gb (gb = 0 for the base)
+    float4 gme[NGRP];
+#pragma unroll
+    for (int g = 0; g < NGRP; g++) gme[g] = sc.grp[g][ln];
     unsigned cand = 0;
+    if (m == 0) {
 #pragma unroll 1
-    for (int c = 0; c < nbc; c++) {
-        const V3 e0 = base_end(c, 0), d = base_end(c, 1) - e0;
-        const float dd = dot(d, d), rdd = dd > 0.0f ? 1.0f / dd : 0.0f, rb = A.base.pts[2 * c][3];
-#pragma unroll
-        for (int ga = 0; ga < NGRP; ga++) {
-            V3 rel = gc[ga] - e0;
-            V3 off = rel - d * fminf(fmaxf(dot(rel, d) * rdd, 0.0f), 1.0f);
-            float lim = gr[ga] + rb + margin;
-            if (dot(off, off) < lim * lim) cand |= 1u << (ga * NGRP);
-        }
-    }
-    __builtin_amdgcn_wave_barrier();               // LDS traffic between the lanes of one wave: in order, no s_barrier
-#pragma unroll
-    for (int m = 1; m < K; m++) {
-#pragma unroll
-        for (int gb = 0; gb < NGRP; gb++) {
-            const float4 o = sc.grp[gb][ln ^ m];
+        for (int c = 0; c < nbc; c++) {
+            const V3 e0 = base_end(c, 0), d = base_end(c, 1) - e0;
+            const float dd = dot(d, d), rdd = dd > 0.0f ? 1.0f / dd : 0.0f, rb = A.base.pts[2 * c][3];
 #pragma unroll
             for (int ga = 0; ga < NGRP; ga++) {
-                V3 off = gc[ga] - xyz(o);
-                float lim = gr[ga] + o.w + margin;
-                if (dot(off, off) < lim * lim) cand |= 1u << ((m * NGRP + ga) * NGRP + gb);
+                V3 rel = xyz(gme[ga]) - e0;
+                V3 off = rel - d * fminf(fmaxf(dot(rel, d) * rdd, 0.0f), 1.0f);
+                float lim = gme[ga].w + rb + margin;
+                if (dot(off, off) < lim * lim) cand |= 1u << (ga * NGRP);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int gb = 0; gb < NGRP; gb++) {
+            const float4 o = sc.grp[gb][lp];
+#pragma unroll
+            for (int ga = 0; ga < NGRP; ga++) {
+                V3 off = xyz(gme[ga]) - xyz(o);
+                float lim = gme[ga].w + o.w + margin;
+                if (dot(off, off) < lim * lim) cand |= 1u << (ga * NGRP + gb);
             }
         }
     }
-    if (__builtin_amdgcn_ballot_w64(cand != 0) == 0) return false;
-    // ---- stage 2 (only waves with a candidate): narrow phase; the limb side is folded into the body's rigid terms, the deepest
-    // base contact is kept for the passes.  Loops are rolled and every trip / pair is skipped wave-uniformly unless flagged.
+    const bool any = __builtin_amdgcn_ballot_w64(cand != 0) != 0;
+    // ---- stage 2: per body of this limb the deepest active pair
 #pragma unroll
-    for (int c = 0; c <= NCAP; c++) sc.frc[c][ln] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    float best = -1e30f, best_f0 = 0.0f; V3 best_cxn = v3(0, 0, 0), best_n = v3(0, 0, 0);
-    const V3 w0 = v3(root[10], root[11], root[12]), v0 = v3(root[7], root[8], root[9]);
-    // limb side of a contact on capsule i against a shape backed by mass mB; returns the force estimate that is exported
-    auto apply = [&](int i, const SelfHit &h, float mB) {
-        const int jc = T::pt_joint(T::cap_p0(i));
-        const float mA = tab[jc * LG_JS + J_SUBM];
-        V3 rj = db[0];
-#pragma unroll
-        for (int jj = 1; jj < L; jj++) if (jj <= jc) rj = rj + db[jj];
-        const V3 r = h.pa - rj, f = h.n * h.f0, rxn = cross(r, h.n);
-#pragma unroll
-        for (int jj = 0; jj < L; jj++) if (jj == jc) {
-            ai_add_rank1(I0[jj], dt * kn * (1.0f + mA / mB), rxn, h.n);
-            p0[jj].w = p0[jj].w - cross(r, f); p0[jj].v = p0[jj].v - f;
-        }
-        const float frep = h.f0 / (1.0f + kn * dt * (1.0f / mA + 1.0f / mB));
-        float4 acc = sc.frc[i][ln];
-        sc.frc[i][ln] = make_float4(acc.x + h.n.x * frep, acc.y + h.n.y * frep, acc.z + h.n.z * frep, 0.0f);
-        return frep;
-    };
-    float best_coef = 0.0f, best_frep = 0.0f;
+    for (int ga = 0; ga < NGRP; ga++) {
+        SelfHit best; best.depth = -1e30f; best.f0 = 0.0f; best.n = best.pa = best.pb = v3(0, 0, 0);
+        float best_mB = 1.0f; int best_i = 0;
+        const unsigned gbits = ((1u << NGRP) - 1u) << (ga * NGRP);
+        if (any && __builtin_amdgcn_ballot_w64((cand & gbits) != 0) != 0) {
 #pragma unroll 1
-    for (int m = 0; m < K; m++) {
-        const unsigned mbits = ((1u << (NGRP * NGRP)) - 1u) << (m * NGRP * NGRP);
-        if (__builtin_amdgcn_ballot_w64((cand & mbits) != 0) == 0) continue;              // nobody near this partner
-        const int lp = ln ^ m;
+            for (int i = T::grp_cap_lo(ga); i < T::grp_cap_hi(ga); i++) {
+                const int ip0 = T::cap_p0(i), ip1 = T::cap_p1(i);
+                const float4 pa0 = sc.pos[ip0][ln], pa1 = sc.pos[ip1][ln];
+                const bool sa = ip0 == ip1;
+                const int nother = m == 0 ? nbc : NCAP;
 #pragma unroll 1
-        for (int i = 0; i < NCAP; i++) {
-            const unsigned ibits = ((1u << NGRP) - 1u) << ((m * NGRP + T::cap_grp(i)) * NGRP);
-            if (__builtin_amdgcn_ballot_w64((cand & ibits) != 0) == 0) continue;
-            const int ip0 = T::cap_p0(i), ip1 = T::cap_p1(i);
-            const float4 pa0 = sc.pos[ip0][ln], pa1 = sc.pos[ip1][ln];
-            const bool sa = ip0 == ip1;
-            const int nother = m == 0 ? nbc : NCAP;
-#pragma unroll 1
-            for (int j = 0; j < nother; j++) {
-                const unsigned bit = 1u << ((m * NGRP + T::cap_grp(i)) * NGRP + (m == 0 ? 0 : T::cap_grp(j)));
-                if (__builtin_amdgcn_ballot_w64((cand & bit) != 0) == 0) continue;
-                SelfHit h; bool hit = false;
-                if (m == 0) {
-                    const V3 e0 = base_end(j, 0), e1 = base_end(j, 1);
-                    auto vel = [&](V3 &va0, V3 &va1, V3 &vb0, V3 &vb1) {
-                        va0 = xyz(sc.vel[ip0][ln]); va1 = xyz(sc.vel[ip1][ln]); vb0 = v0 + cross(w0, e0); vb1 = v0 + cross(w0, e1);
-                    };
-                    if (cand & bit) hit = sa ? capsule_contact<true, false>(P, kn, xyz(pa0), xyz(pa1), pa0.w, e0, e1, A.base.pts[2 * j][3], vel, h)
-                                             : capsule_contact<false, false>(P, kn, xyz(pa0), xyz(pa1), pa0.w, e0, e1, A.base.pts[2 * j][3], vel, h);
-                } else {
-                    const int jp0 = T::cap_p0(j), jp1 = T::cap_p1(j);
-                    const float4 pb0 = sc.pos[jp0][lp], pb1 = sc.pos[jp1][lp];
-                    const bool sb = jp0 == jp1;
-                    auto vel = [&](V3 &va0, V3 &va1, V3 &vb0, V3 &vb1) {
-                        va0 = xyz(sc.vel[ip0][ln]); va1 = xyz(sc.vel[ip1][ln]); vb0 = xyz(sc.vel[jp0][lp]); vb1 = xyz(sc.vel[jp1][lp]);
-                    };
-                    if (cand & bit) {              // the shape kinds are wave-uniform (i, j are loop counters): no divergence from the dispatch
-                        if (sa && sb) hit = capsule_contact<true, true>(P, kn, xyz(pa0), xyz(pa1), pa0.w, xyz(pb0), xyz(pb1), pb0.w, vel, h);
-                        else if (sa) hit = capsule_contact<true, false>(P, kn, xyz(pa0), xyz(pa1), pa0.w, xyz(pb0), xyz(pb1), pb0.w, vel, h);
-                        else if (sb) hit = capsule_contact<false, true>(P, kn, xyz(pa0), xyz(pa1), pa0.w, xyz(pb0), xyz(pb1), pb0.w, vel, h);
-                        else hit = capsule_contact<false, false>(P, kn, xyz(pa0), xyz(pa1), pa0.w, xyz(pb0), xyz(pb1), pb0.w, vel, h);
-                    }
-                }
-                if (__builtin_amdgcn_ballot_w64(hit) != 0) {
-                    if (hit) {
-                        const float mB = m == 0 ? A.base.mass_robot : (tab + ((lp & (K - 1)) - (ln & (K - 1))) * Tab<T>::STRIDE)[T::pt_joint(T::cap_p0(m == 0 ? 0 : j)) * LG_JS + J_SUBM];
-                        const float frep = apply(i, h, mB);
-                        if (m == 0 && h.depth > best) {
-                            best = h.depth; best_f0 = h.f0; best_n = h.n; best_cxn = cross(h.pb, h.n); best_frep = frep;
-                            best_coef = dt * kn * (1.0f + mB / tab[T::pt_joint(T::cap_p0(i)) * LG_JS + J_SUBM]);
+                for (int j = 0; j < nother; j++) {
+                    const unsigned bit = 1u << (ga * NGRP + (m == 0 ? 0 : T::cap_grp(j)));
+                    if (__builtin_amdgcn_ballot_w64((cand & bit) != 0) == 0) continue;                  // wave-uniform skip
+                    SelfHit h; bool hit = false; float mB;
+                    if (m == 0) {
+                        const V3 e0 = base_end(j, 0), e1 = base_end(j, 1);
+                        auto vel = [&](V3 &va0, V3 &va1, V3 &vb0, V3 &vb1) {
+                            va0 = xyz(sc.vel[ip0][ln]); va1 = xyz(sc.vel[ip1][ln]); vb0 = v0 + cross(w0, e0); vb1 = v0 + cross(w0, e1);
+                        };
+                        mB = A.base.mass_robot;
+                        if (cand & bit) hit = sa ? capsule_contact<true, false>(P, kn, xyz(pa0), xyz(pa1), pa0.w, e0, e1, A.base.pts[2 * j][3], vel, h)
+                                                 : capsule_contact<false, false>(P, kn, xyz(pa0), xyz(pa1), pa0.w, e0, e1, A.base.pts[2 * j][3], vel, h);
+                    } else {
+                        const int jp0 = T::cap_p0(j), jp1 = T::cap_p1(j);
+                        const float4 pb0 = sc.pos[jp0][lp], pb1 = sc.pos[jp1][lp];
+                        const bool sb = jp0 == jp1;
+                        auto vel = [&](V3 &va0, V3 &va1, V3 &vb0, V3 &vb1) {
+                            va0 = xyz(sc.vel[ip0][ln]); va1 = xyz(sc.vel[ip1][ln]); vb0 = xyz(sc.vel[jp0][lp]); vb1 = xyz(sc.vel[jp1][lp]);
+                        };
+                        mB = tabp[T::pt_joint(jp0) * LG_JS + J_SUBM];
+                        if (cand & bit) {              // the shape kinds are wave-uniform (i, j are loop counters): no divergence from the dispatch
+                            if (sa && sb) hit = capsule_contact<true, true>(P, kn, xyz(pa0), xyz(pa1), pa0.w, xyz(pb0), xyz(pb1), pb0.w, vel, h);
+                            else if (sa) hit = capsule_contact<true, false>(P, kn, xyz(pa0), xyz(pa1), pa0.w, xyz(pb0), xyz(pb1), pb0.w, vel, h);
+                            else if (sb) hit = capsule_contact<false, true>(P, kn, xyz(pa0), xyz(pa1), pa0.w, xyz(pb0), xyz(pb1), pb0.w, vel, h);
+                            else hit = capsule_contact<false, false>(P, kn, xyz(pa0), xyz(pa1), pa0.w, xyz(pb0), xyz(pb1), pb0.w, vel, h);
                         }
                     }
+                    if (hit && h.depth > best.depth) { best = h; best_mB = mB; best_i = i; }
                 }
             }
         }
+        const bool on = best.depth > -1e29f;
+        const float mA = tab[T::pt_joint(T::grp_c0(ga)) * LG_JS + J_SUBM];
+        sc.rec[m][ga][0][ln] = make_float4(best.n.x, best.n.y, best.n.z, best.f0);
+        sc.rec[m][ga][1][ln] = make_float4(best.pa.x, best.pa.y, best.pa.z, on ? dt * kn * (1.0f + mA / best_mB) : -1.0f);
+        sc.rec[m][ga][2][ln] = make_float4(best.pb.x, best.pb.y, best.pb.z, on ? dt * kn * (1.0f + best_mB / mA) : -1.0f);
+        sc.rec[m][ga][3][ln] = make_float4(best.f0 / (1.0f + kn * dt * (1.0f / mA + 1.0f / best_mB)), (float)best_i, 0.0f, 0.0f);
     }
-    sc.base[0][ln] = make_float4(best_cxn.x, best_cxn.y, best_cxn.z, best > -1e29f ? best_coef : -1.0f);   // w: implicit coefficient, < 0: none
-    sc.base[1][ln] = make_float4(best_n.x, best_n.y, best_n.z, best_f0);
-    if (best > -1e29f) sc.frc[NCAP][ln] = make_float4(-best_n.x * best_frep, -best_n.y * best_frep, -best_n.z * best_frep, 0.0f);
-    return true;
+}
+// Rigid-body wave, before the final pass: fold the limb side of every record into the carrying body's rigid terms.
+// Returns (wave-uniform) whether any lane of the wave has a record.
+template <class T>
+LG_DEV bool self_apply(int ln, const V3 (&db)[T::L], AI (&I0)[T::L], S6 (&p0)[T::L], const SelfLds<T> &sc) {
+    bool any = false;
+#pragma unroll 1
+    for (int m = 0; m < T::K; m++) {
+#pragma unroll
+        for (int g = 0; g < T::NGRP; g++) {
+            constexpr int dummy = 0; (void)dummy;
+            const int jc = T::pt_joint(T::grp_c0(g));                     // compile time after unrolling
+            const float4 r1 = sc.rec[m][g][1][ln];
+            const bool hit = r1.w >= 0.0f;
+            if (__builtin_amdgcn_ballot_w64(hit) == 0) continue;
+            any = true;
+            if (hit) {
+                const float4 r0 = sc.rec[m][g][0][ln];
+                V3 rj = db[0];
+#pragma unroll
+                for (int jj = 1; jj <= jc; jj++) rj = rj + db[jj];
+                const V3 n = xyz(r0), r = xyz(r1) - rj, f = n * r0.w;
+                ai_add_rank1(I0[jc], r1.w, cross(r, n), n);
+                p0[jc].w = p0[jc].w - cross(r, f); p0[jc].v = p0[jc].v - f;
+            }
+        }
+    }
+    return any;
 }
 
 // `torques_ready` runs between the kinematics half (needs no torques) and the articulated-body passes: the fused step
@@ -462,7 +475,8 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, int lane_k, float 
                             const float (&tau)[T::L], float base_mass, float mu,
                             float (&Frep)[T::NREP][3], float (&Fbase)[3], Ready torques_ready = Ready(),
                             const float4 (*bt)[LG_BT_QUADS][LG_BLOCK] = nullptr, float4 (*fkout)[4][LG_BLOCK] = nullptr,
-                            volatile int *fk_ready = nullptr, int substep_no = 0, SelfLds<T> *sc = nullptr, bool last = true) {
+                            volatile int *fk_ready = nullptr, int substep_no = 0, SelfLds<T> *sc = nullptr, bool last = true,
+                            bool sc_on_helpers = false /* the three helper waves run self_detect (four-wave kernels) */) {
     constexpr int K = T::K, L = T::L, NPT = T::NPT;
     const lg_params &P = A.P;
     const float dt = P.sim_dt;
@@ -564,6 +578,14 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, int lane_k, float 
         }
     }
 
+    if constexpr (SC) {                                    // group bounds and base pose for the detection (helper waves, after the hand-over barrier)
+        const int ln = threadIdx.x % LG_BLOCK;
+#pragma unroll
+        for (int g = 0; g < T::NGRP; g++) sc->grp[g][ln] = make_float4(sgc[g].x, sgc[g].y, sgc[g].z, tab[Tab<T>::GRP + g]);
+        sc->basepose[0][ln] = make_float4(R0.m[0], R0.m[1], R0.m[2], 0.0f); sc->basepose[1][ln] = make_float4(R0.m[3], R0.m[4], R0.m[5], 0.0f);
+        sc->basepose[2][ln] = make_float4(R0.m[6], R0.m[7], R0.m[8], 0.0f);
+        sc->basepose[3][ln] = make_float4(w0.x, w0.y, w0.z, 0.0f); sc->basepose[4][ln] = make_float4(v0.x, v0.y, v0.z, 0.0f);
+    }
     LG_PROF(PF_KINEMATICS);
     torques_ready();
     if (OFFLOAD) {
@@ -571,7 +593,6 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, int lane_k, float 
         for (int j = 0; j < L; j++) bt_load(bt[j], threadIdx.x % LG_BLOCK, I0[j], p0[j]);
     }
     bool any_self = false;                                 // wave-uniform
-    if constexpr (SC) any_self = self_collide<T>(A, tab, threadIdx.x % LG_BLOCK, root, db, sgc, I0, p0, *sc);
     LG_PROF(PF_TORQUE);
     // ---- articulated-body passes with the contact impedances folded in
     S6 U[L], acc0;
@@ -581,6 +602,22 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, int lane_k, float 
 #pragma unroll 1
     for (int pass = 0; pass < LG_PASSES; pass++) {
         AI Ia; S6 pa;
+        if constexpr (SC) if (pass == LG_PASSES - 1) {     // self-collision records enter the final pass
+            const int ln = threadIdx.x % LG_BLOCK;
+            if (sc_on_helpers) {                           // detection ran on the helper waves during the first pass
+                volatile int *rdy = sc->ready;
+#pragma unroll
+                for (int w = 1; w < LG_STEP_WAVES; w++)
+                    for (int spin = 0; rdy[w] < substep_no && spin < (1 << 22); spin++) __builtin_amdgcn_s_sleep(1);     // bounded, like the fk hand-over
+                __builtin_amdgcn_wave_barrier();
+            } else {
+                __builtin_amdgcn_wave_barrier();           // this wave's own LDS writes (kinematics loop) precede the reads: one wave, in order
+#pragma unroll 1
+                for (int m = 0; m < K; m++) self_detect<T>(A, tab - lane_k * Tab<T>::STRIDE, ln, m, *sc);
+                __builtin_amdgcn_wave_barrier();
+            }
+            any_self = self_apply<T>(ln, db, I0, p0, *sc);
+        }
 #pragma unroll
         for (int j = L - 1; j >= 0; j--) {
             const float *tj = tab + j * LG_JS;
@@ -616,11 +653,17 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, int lane_k, float 
         }
         LG_PROF(PF_INWARD);
         contact_assemble(cb, P, kn, Ia, pa);      // this lane's base point (about the base origin, like Ia after the shift)
-        if (SC && any_self) {                     // reaction of this limb's deepest base contact: force -n f0 on the base, implicit in the base's motion
-            const float4 s0 = sc->base[0][threadIdx.x % LG_BLOCK], s1 = sc->base[1][threadIdx.x % LG_BLOCK];
-            if (s0.w >= 0.0f) {
-                ai_add_rank1(Ia, s0.w, xyz(s0), xyz(s1));
-                pa.w = pa.w + xyz(s0) * s1.w; pa.v = pa.v + xyz(s1) * s1.w;
+        if (SC && any_self) {                     // (final pass only) reactions of this limb's base contacts: force -n f0 on the base, implicit in the base's motion
+            const int ln = threadIdx.x % LG_BLOCK;
+#pragma unroll
+            for (int g = 0; g < T::NGRP; g++) {
+                const float4 r2 = sc->rec[0][g][2][ln];
+                if (r2.w >= 0.0f) {
+                    const float4 r0 = sc->rec[0][g][0][ln];
+                    const V3 n = xyz(r0), cxn = cross(xyz(r2), n);
+                    ai_add_rank1(Ia, r2.w, cxn, n);
+                    pa.w = pa.w + cxn * r0.w; pa.v = pa.v + n * r0.w;
+                }
             }
         }
         group_sum<K>(Ia, pa);                     // (limb0+limb1)+(limb2+limb3) on every lane of the env
@@ -681,15 +724,27 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, int lane_k, float 
         Frep[r][0] = f.x; Frep[r][1] = f.y; Frep[r][2] = f.z;
     }
     Fbase[0] = group_sum<K>(cb.f.x); Fbase[1] = group_sum<K>(cb.f.y); Fbase[2] = group_sum<K>(cb.f.z);
-    if (SC && last && any_self) {                 // exported net contact forces include the self-collision forces
+    if (SC && last && any_self) {                 // exported net contact forces include the self-collision forces (estimate of the record)
         const int ln = threadIdx.x % LG_BLOCK;
+        V3 fb = v3(0, 0, 0);
+#pragma unroll 1
+        for (int m = 0; m < K; m++) {
 #pragma unroll
-        for (int c = 0; c < T::NCAP; c++) {
-            const float4 f = sc->frc[c][ln];
-            const int r = T::pt_rep(T::cap_p0(c));
-            Frep[r][0] += f.x; Frep[r][1] += f.y; Frep[r][2] += f.z;
+            for (int g = 0; g < T::NGRP; g++) {
+                const float4 r1 = sc->rec[m][g][1][ln];
+                if (r1.w >= 0.0f) {
+                    const float4 r0 = sc->rec[m][g][0][ln], r3 = sc->rec[m][g][3][ln];
+                    const V3 f = xyz(r0) * r3.x;
+                    const int ci = (int)r3.y;
+#pragma unroll
+                    for (int c = T::grp_cap_lo(g); c < T::grp_cap_hi(g); c++) if (c == ci) {
+                        const int r = T::pt_rep(T::cap_p0(c));
+                        Frep[r][0] += f.x; Frep[r][1] += f.y; Frep[r][2] += f.z;
+                    }
+                    if (m == 0) fb = fb - f;
+                }
+            }
         }
-        const float4 fb = sc->frc[T::NCAP][ln];
         Fbase[0] += group_sum<K>(fb.x); Fbase[1] += group_sum<K>(fb.y); Fbase[2] += group_sum<K>(fb.z);
     }
     LG_PROF(PF_INTEGRATE);
@@ -731,7 +786,6 @@ LG_DEV float wrap_to_pi(float a) {                                              
 // thread (wave, lane = (env, limb k)) is virtual lane k + K * wave and keeps its chunks' heights in registers between
 // sampling (before the reset decision) and the observation (after it, Q7).  All 3*4*NCH gathers are issued before the
 // first one is consumed (the samples are L2-resident but ~1 us away for a lone wave).
-#define LG_STEP_WAVES 4
 template <class T, int NW = LG_STEP_WAVES> struct HeightCrew {
     static constexpr int NV = T::K * NW;
     static constexpr int NCH = ((LG_MAX_HEIGHT_POINTS + 3) / 4 + NV - 1) / NV;     // chunks per thread: 3 (K = 4) / 6 (K = 2)
@@ -998,12 +1052,13 @@ struct EpisodeSums {
     }
 };
 
-template <class T, bool NET, bool HF, int NW> struct HelperWave {
+template <class T, bool NET, bool HF, int NW, bool SC = false> struct HelperWave {
     // wave = 1 .. LG_STEP_WAVES-1; with the actuator net also the LSTM of joint (wave - 1); all 64 lanes active
     static constexpr bool OFF = NW >= 2;                         // the helpers also compute (I0, p0) of the limb bodies each sub-step:
                                                                  // wave w takes bodies w-1, w-1 + (NW-1), ...
     static LG_DEV void run(const KArgs &A, int wave, int lane, int e, int k, int d0, bool live, int64_t step, const float *tab,
-                           float2 (*lds_x)[LG_BLOCK], float (*lds_tau)[LG_BLOCK], StepSharedT<OFF, T::L> &sh) {
+                           float2 (*lds_x)[LG_BLOCK], float (*lds_tau)[LG_BLOCK], StepSharedT<OFF, T::L> &sh, SelfLds<T> *sc = nullptr,
+                           const float *lds_tab = nullptr) {
         const lg_buffers &B = A.B;
         const lg_params &P = A.P;
         const int j = wave - 1;
@@ -1052,6 +1107,12 @@ template <class T, bool NET, bool HF, int NW> struct HelperWave {
                     }
                 }
                 __syncthreads();                                   // torques / body terms published
+                if constexpr (SC && NW == LG_STEP_WAVES) {         // self-collision detection in the shadow of the rigid-body wave's first pass:
+                    self_detect<T>(A, lds_tab, lane, wave, *sc);   // this wave's partner limb for all 64 lanes ...
+                    if (wave == 1) self_detect<T>(A, lds_tab, lane, 0, *sc);      // ... and the base
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (lane == 0) sc->ready[wave] = it + 1;
+                }
             }
         }
         __syncthreads();                                           // P1: final poses published
@@ -1112,6 +1173,7 @@ __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
     __shared__ float lds_act[POL ? 16 : 1][16];                 // sampled actions [action][env in block]
     LG_PROF_BEGIN();
     if (threadIdx.x == 0) sh.fk_ready = 0;                      // published before the first use by stage_limb_table's barrier
+    if constexpr (SC) { if (threadIdx.x < LG_STEP_WAVES) sc_store.get()->ready[threadIdx.x] = 0; }
     stage_limb_table<T>(A, lds_tab);
 
     const int N = P.num_envs;
@@ -1130,7 +1192,7 @@ __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
         __syncthreads();
     }
     if (wave > 0) {
-        HelperWave<T, NET, HF, NW>::run(A, wave, lane, e, k, d0, live, step, tab, lds_x, lds_tau, sh);
+        HelperWave<T, NET, HF, NW, SC>::run(A, wave, lane, e, k, d0, live, step, tab, lds_x, lds_tau, sh, sc_store.get(), lds_tab);
     } else {
     // ---- load persistent state (read once per env-step)
     float root[13], q[L], qd[L], act[L], tau[L];
@@ -1181,7 +1243,7 @@ __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
                 }
             };
             physics_substep<T, HF, decltype(join), OFF, SC>(A, tab, k, root, q, qd, tau, base_mass, mu, Frep, Fbase, join, sh.bt, sh.fk, &sh.fk_ready, it + 1,
-                                                            sc_store.get(), it == P.decimation - 1);
+                                                            sc_store.get(), it == P.decimation - 1, SC && NW == LG_STEP_WAVES);
         } else {
             physics_substep<T, HF, NoWait, false, SC>(A, tab, k, root, q, qd, tau, base_mass, mu, Frep, Fbase, NoWait(), nullptr, nullptr, nullptr, 0,
                                                       sc_store.get(), it == P.decimation - 1);

@@ -284,7 +284,10 @@ static inline float motor_torque(float tau, float qd, float vlim) {
  *   - shapes: consecutive collision points on the same body with equal radius form a capsule (segment + radius), a single
  *     point is a sphere (ANYmal-C limb: KFE-drive capsule on the THIGH, shank capsule, foot sphere; base capsule);
  *   - pairs: every limb capsule against the base capsules and against the capsules of every OTHER limb (links of one limb
- *     are adjacent or out of each other's reach); closest points of the two segments, depth = ra + rb - distance;
+ *     are adjacent or out of each other's reach); closest points of the two segments, depth = ra + rb - distance.  Per limb
+ *     BODY and partner (the base, each other limb) the DEEPEST active pair is the contact of this sub-step;
+ *   - when: detection uses the state at the start of the sub-step; the contact terms enter the LAST articulated-body pass
+ *     only (the HIP kernel detects on its helper waves while the rigid-body wave runs the first pass);
  *   - force: frictionless implicit spring-damper along the contact normal, bias s = max(0, K d - kappa v_n) with v_n the relative
  *     normal velocity at the start of the sub-step; active while the shapes overlap (d > 0), and in the speculative range
  *     -contact_margin < d <= 0 when K d - kappa v_n > 0 (approaching fast enough to touch within the step);
@@ -346,7 +349,7 @@ static int build_capsules(const lg_robot_model *M, int g, int L, const float (*R
     return n;
 }
 
-typedef struct { int on; float depth, f0, coef, frep; v3 cxn, n; } base_slot_t;     /* reaction of a limb's deepest base contact */
+typedef struct { int on, body, report; float depth, f0, coef, coef_other, frep; v3 n, pa, pb; } self_rec_t;   /* deepest contact of a limb with one partner */
 
 /* one capsule pair: A (on a limb body) against B.  Returns 1 and fills (n: from B to A, depth, f0, contact points) when active. */
 static int capsule_contact(const lg_params *P, const capsule_t *A, const capsule_t *B, float kn, v3 *n, float *depth, float *f0, v3 *pa, v3 *pb) {
@@ -479,40 +482,36 @@ static void physics_substep_env(const lgo_sim *s, int e, const float *tau, int w
         p0[b].v = sub(cross(wb[b], l), fg);
     }
 
-    /* ---- self-collision: folded into the rigid-body terms of the limb bodies; base reactions kept per limb */
-    base_slot_t bslot[LG_MAX_LIMBS];
+    /* ---- self-collision: per limb and partner (0 = base, m > 0 = limb k ^ m) the deepest active capsule pair */
+    self_rec_t srec[LG_MAX_LIMBS][LG_MAX_LIMBS][LG_MAX_CHAIN];     /* [limb][partner][joint of the carrying body] */
     float self_cf[LG_MAX_BODIES][3];
     memset(self_cf, 0, sizeof self_cf);
-    for (int k = 0; k < K; k++) bslot[k].on = 0;
+    for (int k = 0; k < K; k++) for (int m = 0; m < K; m++) for (int j = 0; j < L; j++) srec[k][m][j].on = 0;
     if (P->self_collision) {
         const float kn_s = P->contact_stiffness * dt + P->contact_damping;
         capsule_t cbase[LG_MAX_BASE_POINTS], climb[LG_MAX_LIMBS][LG_MAX_LIMB_POINTS];
         int nbase = build_capsules(M, -1, L, Rb, rb, wb, vb, cbase), nl[LG_MAX_LIMBS];
         for (int k = 0; k < K; k++) nl[k] = build_capsules(M, k, L, Rb, rb, wb, vb, climb[k]);
-        for (int k = 0; k < K; k++) {
-            for (int m = 0; m < K; m++) {              /* m = 0: the base; m > 0: limb k ^ m (the lane's DPP partner order) */
-                const capsule_t *other = (m == 0) ? cbase : climb[k ^ m];
-                int no = (m == 0) ? nbase : nl[k ^ m];
-                if (m > 0 && (k ^ m) >= K) continue;
-                for (int i = 0; i < nl[k]; i++) for (int j = 0; j < no; j++) {
-                    const capsule_t *A = &climb[k][i];
-                    v3 n, pa, pb; float depth, f0;
-                    if (!capsule_contact(P, A, &other[j], kn_s, &n, &depth, &f0, &pa, &pb)) continue;
-                    const float mA = A->mhat, mB = other[j].mhat;
-                    v3 r = sub(pa, rb[A->body]);                          /* arm about the body's own joint origin */
-                    ai_add_rank1(&I0[A->body], dt * kn_s * (1.0f + mA / mB), cross(r, n), n);
-                    v3 f = scl(n, f0);
-                    p0[A->body].w = sub(p0[A->body].w, cross(r, f));
-                    p0[A->body].v = sub(p0[A->body].v, f);
-                    float frep = f0 / (1.0f + kn_s * dt * (1.0f / mA + 1.0f / mB));
-                    self_cf[A->report][0] += n.x * frep; self_cf[A->report][1] += n.y * frep; self_cf[A->report][2] += n.z * frep;
-                    if (m == 0 && (!bslot[k].on || depth > bslot[k].depth)) {
-                        bslot[k].on = 1; bslot[k].depth = depth; bslot[k].f0 = f0; bslot[k].n = n; bslot[k].cxn = cross(pb, n);
-                        bslot[k].coef = dt * kn_s * (1.0f + mB / mA); bslot[k].frep = frep;
-                    }
-                }
+        for (int k = 0; k < K; k++) for (int m = 0; m < K; m++) {
+            if (m > 0 && (k ^ m) >= K) continue;
+            const capsule_t *other = (m == 0) ? cbase : climb[k ^ m];
+            const int no = (m == 0) ? nbase : nl[k ^ m];
+            for (int i = 0; i < nl[k]; i++) for (int j = 0; j < no; j++) {
+                const capsule_t *A = &climb[k][i];
+                self_rec_t *r = &srec[k][m][A->body - 1 - k * L];
+                v3 n, pa, pb; float depth, f0;
+                if (!capsule_contact(P, A, &other[j], kn_s, &n, &depth, &f0, &pa, &pb)) continue;
+                if (r->on && !(depth > r->depth)) continue;
+                const float mA = A->mhat, mB = other[j].mhat;
+                r->on = 1; r->body = A->body; r->report = A->report; r->depth = depth; r->f0 = f0; r->n = n; r->pa = pa; r->pb = pb;
+                r->coef = dt * kn_s * (1.0f + mA / mB); r->coef_other = dt * kn_s * (1.0f + mB / mA);
+                r->frep = f0 / (1.0f + kn_s * dt * (1.0f / mA + 1.0f / mB));
             }
-            if (bslot[k].on) { self_cf[0][0] -= bslot[k].n.x * bslot[k].frep; self_cf[0][1] -= bslot[k].n.y * bslot[k].frep; self_cf[0][2] -= bslot[k].n.z * bslot[k].frep; }
+            for (int jb = 0; jb < L; jb++) if (srec[k][m][jb].on) {
+                const self_rec_t *r = &srec[k][m][jb];
+                self_cf[r->report][0] += r->n.x * r->frep; self_cf[r->report][1] += r->n.y * r->frep; self_cf[r->report][2] += r->n.z * r->frep;
+                if (m == 0) { self_cf[0][0] -= r->n.x * r->frep; self_cf[0][1] -= r->n.y * r->frep; self_cf[0][2] -= r->n.z * r->frep; }
+            }
         }
     }
 
@@ -559,6 +558,14 @@ static void physics_substep_env(const lgo_sim *s, int e, const float *tau, int w
     for (int b = 0; b <= nd; b++) vl[b] = 0.0f;
     for (int pass = 0; pass < LG_CONTACT_PASSES; pass++) {
         ai6 IA[NB]; sv6 pA[NB];
+        if (pass == LG_CONTACT_PASSES - 1)          /* self-collision: limb side folded into the bodies' rigid terms for the final pass */
+            for (int k = 0; k < K; k++) for (int m = 0; m < K; m++) for (int jb = 0; jb < L; jb++) if (srec[k][m][jb].on) {
+                const self_rec_t *r = &srec[k][m][jb];
+                v3 arm = sub(r->pa, rb[r->body]), f = scl(r->n, r->f0);       /* arm about the body's own joint origin */
+                ai_add_rank1(&I0[r->body], r->coef, cross(arm, r->n), r->n);
+                p0[r->body].w = sub(p0[r->body].w, cross(arm, f));
+                p0[r->body].v = sub(p0[r->body].v, f);
+            }
         for (int b = 0; b <= nd; b++) { IA[b] = I0[b]; pA[b] = p0[b]; }
         ai6 IBp[LG_MAX_LIMBS]; sv6 pBp[LG_MAX_LIMBS];     /* base point i's terms ride with limb i (HIP: lane i owns base point i) */
         for (int k = 0; k < K; k++) { ai_zero(&IBp[k]); pBp[k].w = V(0, 0, 0); pBp[k].v = V(0, 0, 0); }
@@ -574,11 +581,14 @@ static void physics_substep_env(const lgo_sim *s, int e, const float *tau, int w
             pt_->w = sub(pt_->w, cross(c->r, f));
             pt_->v = sub(pt_->v, f);
         }
-        for (int k = 0; k < K; k++) if (bslot[k].on) {      /* reaction of limb k's deepest base contact: force -n f on the base */
-            ai_add_rank1(&IBp[k], bslot[k].coef, bslot[k].cxn, bslot[k].n);
-            pBp[k].w = add(pBp[k].w, scl(bslot[k].cxn, bslot[k].f0));
-            pBp[k].v = add(pBp[k].v, scl(bslot[k].n, bslot[k].f0));
-        }
+        if (pass == LG_CONTACT_PASSES - 1)
+            for (int k = 0; k < K; k++) for (int jb = 0; jb < L; jb++) if (srec[k][0][jb].on) {      /* reactions of limb k's base contacts: force -n f on the base */
+                const self_rec_t *r = &srec[k][0][jb];
+                v3 cxn = cross(r->pb, r->n);
+                ai_add_rank1(&IBp[k], r->coef_other, cxn, r->n);
+                pBp[k].w = add(pBp[k].w, scl(cxn, r->f0));
+                pBp[k].v = add(pBp[k].v, scl(r->n, r->f0));
+            }
         for (int k = 0; k < K; k++) for (int j = L - 1; j >= 0; j--) {
             int d = k * L + j, b = 1 + d, par = (j == 0) ? 0 : b - 1;
             float q = dof[2 * d], qd = dof[2 * d + 1];
