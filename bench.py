@@ -250,6 +250,34 @@ def worker(a):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)           # per region: the slowest rank
     elapsed = float(t.median().item()) if repeats > 1 else float(t[0].item())
 
+    # cost of self-collision (on in the anymal_c_flat config): the same rollout with asset.self_collisions switched off
+    sc_cost = None
+    if getattr(env, "self_collision_modelled", False) and world == 1 and fused_step and not a.no_graph:
+        try:
+            env_cfg2, _ = task_registry.get_cfgs(a.task)
+            keep = env_cfg2.asset.self_collisions
+            env_cfg2.asset.self_collisions = 1
+            with contextlib.redirect_stdout(io.StringIO()):
+                env2, _ = task_registry.make_env(a.task, args, env_cfg=env_cfg2)
+                env2.set_fixed_commands(0.5, 0.0, 0.0)
+                env2.reset()
+            env_cfg2.asset.self_collisions = keep
+            with torch.inference_mode():
+                fused2 = FusedActor(policy, dev, seed=train_cfg.seed + rank, step_counter=env2._sim.buf["step_counter"])
+                step2 = env2.make_graphed_policy_step(fused2, steps_per_replay=20)
+                for _ in range(5):
+                    step2()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(50):
+                    step2()
+                torch.cuda.synchronize()
+                ms_off = 1e3 * (time.perf_counter() - t0) / 1000
+            sc_cost = {"ms_per_step_without_self_collision": ms_off, "note": "same rollout, asset.self_collisions = 1 (1000 steps)"}
+            del env2, fused2, step2
+        except Exception as exc:
+            sc_cost = {"error": f"{type(exc).__name__}: {exc}"}
+
     training = None
     iters = a.training_iters if a.training_iters >= 0 else (100 if a.task == "anymal_c_flat" else 20)
     if iters > 0:
@@ -301,6 +329,10 @@ def worker(a):
                                    "note": "counted fp32 flops of the timed kernel (tools/flop_count.py: ABA + contacts, actuator LSTM, actor when fused) / fp32 vector peak"},
                          "note": "issue/latency-bound, not HBM-bound: one 512-register rigid-body wave per SIMD runs a serial chain of ~20k instructions; state is L2/MALL-resident; see DESIGN.md section 5"},
         }
+        if sc_cost is not None:
+            if "ms_per_step_without_self_collision" in sc_cost:
+                sc_cost["self_collision_cost_ms_per_step"] = out["ms_per_step"] - sc_cost["ms_per_step_without_self_collision"]
+            out["self_collision"] = sc_cost
         if world > 1:
             out["rccl_ranks" if backend == "nccl" else f"{backend}_ranks"] = ranks_seen
         if training is not None:

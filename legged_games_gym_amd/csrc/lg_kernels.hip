@@ -233,20 +233,22 @@ LG_DEV void body_terms(V3 grav, float m, V3 com_l, const float *Il, const M3 &R,
 // one joint of the forward-kinematics chain (world axes): parent frame (Rpar, wpar, vpar) -> this body's frame
 struct FkOut { M3 R; V3 db, ax, w, v; };
 LG_DEV FkOut fk_joint(const float *tj, const M3 &Rpar, V3 wpar, V3 vpar, float q, float qd) {
+    // The host re-frames every body so that its joint axis is the local +x axis (fill_limb_table: "axis alignment"): the
+    // joint rotation then mixes columns 1 and 2 of Rpar * Rfix and leaves column 0 = the world axis.
     FkOut o;
     o.db = mul(Rpar, v3(tj[J_POS], tj[J_POS + 1], tj[J_POS + 2]));
     M3 Rfix;
 #pragma unroll
     for (int i = 0; i < 9; i++) Rfix.m[i] = tj[J_ROT + i];
     const M3 Rz = mul(Rpar, Rfix);
-    o.ax = mul(Rz, v3(tj[J_AXIS], tj[J_AXIS + 1], tj[J_AXIS + 2]));
+    o.ax = v3(Rz.m[0], Rz.m[3], Rz.m[6]);
     float sn, cs;
     __sincosf(q, &sn, &cs);               // v_sin/v_cos (|q| stays within a few rad; abs err ~1e-6)
 #pragma unroll
-    for (int c = 0; c < 3; c++) {
-        V3 col = v3(Rz.m[c], Rz.m[3 + c], Rz.m[6 + c]);
-        V3 rot = (col * cs + cross(o.ax, col) * sn) + o.ax * (dot(o.ax, col) * (1.0f - cs));
-        o.R.m[c] = rot.x; o.R.m[3 + c] = rot.y; o.R.m[6 + c] = rot.z;
+    for (int r = 0; r < 3; r++) {
+        o.R.m[3 * r] = Rz.m[3 * r];
+        o.R.m[3 * r + 1] = cs * Rz.m[3 * r + 1] + sn * Rz.m[3 * r + 2];
+        o.R.m[3 * r + 2] = cs * Rz.m[3 * r + 2] - sn * Rz.m[3 * r + 1];
     }
     o.w = wpar + o.ax * qd;
     o.v = vpar + cross(wpar, o.db);
@@ -285,7 +287,7 @@ template <class T> struct SelfLds {
     float4 grp[T::NGRP][LG_BLOCK];       // bounding sphere of each point group (= shapes of one body): centre, radius
     float4 basepose[5][LG_BLOCK];        // rows of the base rotation, base angular and linear velocity (of the lane's env)
     float4 rec[T::K][T::NGRP][LG_SC_REC][LG_BLOCK];   // deepest contact of body g of this lane's limb with partner m (0: base; m: limb k ^ m); coef < 0: none
-    int    ready[LG_STEP_WAVES];         // helper wave w: sub-step number once its records are complete
+    alignas(16) int ready[LG_STEP_WAVES];   // helper wave w: sub-step number once its records are complete
 };
 LG_DEV V3 xyz(float4 a) { return v3(a.x, a.y, a.z); }
 // closest points of two segments, parameters in [0,1] (Ericson, RTCD 5.1.9); SA / SB: that "segment" is a point (compile time)
@@ -439,19 +441,26 @@ LG_DEV void self_detect(const KArgs &A, const float *lds_tab, int ln, int m, Sel
 // Returns (wave-uniform) whether any lane of the wave has a record.
 template <class T>
 LG_DEV bool self_apply(int ln, const V3 (&db)[T::L], AI (&I0)[T::L], S6 (&p0)[T::L], const SelfLds<T> &sc) {
-    bool any = false;
-#pragma unroll 1
+    float coef[T::K][T::NGRP];                                        // all record headers in flight at once (one LDS latency, not K * NGRP)
+    unsigned mask = 0;
+#pragma unroll
+    for (int m = 0; m < T::K; m++)
+#pragma unroll
+        for (int g = 0; g < T::NGRP; g++) coef[m][g] = sc.rec[m][g][1][ln].w;
+#pragma unroll
+    for (int m = 0; m < T::K; m++)
+#pragma unroll
+        for (int g = 0; g < T::NGRP; g++) if (coef[m][g] >= 0.0f) mask |= 1u << (m * T::NGRP + g);
+    if (__builtin_amdgcn_ballot_w64(mask != 0) == 0) return false;
+#pragma unroll
     for (int m = 0; m < T::K; m++) {
 #pragma unroll
         for (int g = 0; g < T::NGRP; g++) {
-            constexpr int dummy = 0; (void)dummy;
             const int jc = T::pt_joint(T::grp_c0(g));                     // compile time after unrolling
-            const float4 r1 = sc.rec[m][g][1][ln];
-            const bool hit = r1.w >= 0.0f;
+            const bool hit = (mask >> (m * T::NGRP + g)) & 1u;
             if (__builtin_amdgcn_ballot_w64(hit) == 0) continue;
-            any = true;
             if (hit) {
-                const float4 r0 = sc.rec[m][g][0][ln];
+                const float4 r0 = sc.rec[m][g][0][ln], r1 = sc.rec[m][g][1][ln];
                 V3 rj = db[0];
 #pragma unroll
                 for (int jj = 1; jj <= jc; jj++) rj = rj + db[jj];
@@ -461,7 +470,7 @@ LG_DEV bool self_apply(int ln, const V3 (&db)[T::L], AI (&I0)[T::L], S6 (&p0)[T:
             }
         }
     }
-    return any;
+    return true;
 }
 
 // `torques_ready` runs between the kinematics half (needs no torques) and the articulated-body passes: the fused step
@@ -605,10 +614,12 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, int lane_k, float 
         if constexpr (SC) if (pass == LG_PASSES - 1) {     // self-collision records enter the final pass
             const int ln = threadIdx.x % LG_BLOCK;
             if (sc_on_helpers) {                           // detection ran on the helper waves during the first pass
-                volatile int *rdy = sc->ready;
-#pragma unroll
-                for (int w = 1; w < LG_STEP_WAVES; w++)
-                    for (int spin = 0; rdy[w] < substep_no && spin < (1 << 22); spin++) __builtin_amdgcn_s_sleep(1);     // bounded, like the fk hand-over
+                volatile int4 *rdy = reinterpret_cast<volatile int4 *>(sc->ready);       // one read covers the three helpers' flags
+                for (int spin = 0; spin < (1 << 22); spin++) {                             // bounded, like the fk hand-over
+                    const int r1 = rdy->y, r2 = rdy->z, r3 = rdy->w;
+                    if (min(r1, min(r2, r3)) >= substep_no) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
                 __builtin_amdgcn_wave_barrier();
             } else {
                 __builtin_amdgcn_wave_barrier();           // this wave's own LDS writes (kinematics loop) precede the reads: one wave, in order
@@ -1109,7 +1120,7 @@ template <class T, bool NET, bool HF, int NW, bool SC = false> struct HelperWave
                 __syncthreads();                                   // torques / body terms published
                 if constexpr (SC && NW == LG_STEP_WAVES) {         // self-collision detection in the shadow of the rigid-body wave's first pass:
                     self_detect<T>(A, lds_tab, lane, wave, *sc);   // this wave's partner limb for all 64 lanes ...
-                    if (wave == 1) self_detect<T>(A, lds_tab, lane, 0, *sc);      // ... and the base
+                    if (wave == LG_STEP_WAVES - 1) self_detect<T>(A, lds_tab, lane, 0, *sc);      // ... and (the diagonal partner's wave) the base
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     if (lane == 0) sc->ready[wave] = it + 1;
                 }
@@ -1668,15 +1679,54 @@ template <class T> static int check_topology(const lg_robot_model *m) {
     return 1;
 }
 
+// 3x3 helpers for the host-side re-framing (row-major doubles)
+static void m3_mul(const double *A, const double *B, double *C) { for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j]; }
+static void m3_tr(const double *A, double *B) { for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) B[3 * i + j] = A[3 * j + i]; }
+static void m3_vec(const double *A, const float *v, float *out) { for (int i = 0; i < 3; i++) out[i] = (float)(A[3 * i] * v[0] + A[3 * i + 1] * v[1] + A[3 * i + 2] * v[2]); }
+// rotation Q with Q e_x = a (a unit)
+static void m3_align_x(const float *a, double *Q) {
+    double ax = a[0], ay = a[1], az = a[2], n = sqrt(ax * ax + ay * ay + az * az);
+    ax /= n; ay /= n; az /= n;
+    double bx, by, bz;                              // any unit vector orthogonal to a: cross with the coordinate axis least aligned with it
+    if (fabs(ax) <= fabs(ay) && fabs(ax) <= fabs(az)) { bx = 0; by = -az; bz = ay; }
+    else if (fabs(ay) <= fabs(az)) { bx = az; by = 0; bz = -ax; }
+    else { bx = -ay; by = ax; bz = 0; }
+    n = sqrt(bx * bx + by * by + bz * bz); bx /= n; by /= n; bz /= n;
+    const double cx = ay * bz - az * by, cy = az * bx - ax * bz, cz = ax * by - ay * bx;
+    Q[0] = ax; Q[1] = bx; Q[2] = cx; Q[3] = ay; Q[4] = by; Q[5] = cy; Q[6] = az; Q[7] = bz; Q[8] = cz;
+    if (fabs(ax - 1.0) < 1e-12) { for (int i = 0; i < 9; i++) Q[i] = (i % 4 == 0) ? 1.0 : 0.0; }      // already +x: keep the frame
+}
+
 template <class T> static void fill_limb_table(const lg_params &P, const lg_robot_model &M, float *t) {
     memset(t, 0, sizeof(float) * T::K * Tab<T>::STRIDE);
     for (int k = 0; k < T::K; k++) {
         float *tk = t + k * Tab<T>::STRIDE;
+        // Axis alignment: body j's frame is re-defined as B'_j = B_j Q_j with Q_j e_x = joint axis j, so that the kernel's joint
+        // rotation is always about the local +x axis (a 2-column mix instead of a general Rodrigues rotation).  With
+        // R_j = R_par Rfix_j Rot(a_j, q) and Rot(a_j, q) Q_j = Q_j Rot(e_x, q):  R'_j = R'_par [Q_par^T Rfix_j Q_j] Rot(e_x, q);
+        // joint origins are expressed in the parent's new frame (Q_par^T pos), body-local vectors in the body's (Q_j^T v), the
+        // inertia tensor as Q_j^T I Q_j.  World-frame results are unchanged.
+        double Q[T::L][9], Qpar[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
         for (int j = 0; j < T::L; j++) {
             int d = k * T::L + j;
             float *tj = tk + j * LG_JS;
-            memcpy(tj + J_POS, M.joint_pos[d], 12); memcpy(tj + J_ROT, M.joint_rot[d], 36); memcpy(tj + J_AXIS, M.joint_axis[d], 12);
-            tj[J_MASS] = M.body_mass[d]; memcpy(tj + J_COM, M.body_com[d], 12); memcpy(tj + J_INERTIA, M.body_inertia[d], 24);
+            m3_align_x(M.joint_axis[d], Q[j]);
+            double QparT[9], QjT[9], Rf[9], tmp[9], Rnew[9];
+            m3_tr(Qpar, QparT); m3_tr(Q[j], QjT);
+            for (int i = 0; i < 9; i++) Rf[i] = M.joint_rot[d][i];
+            m3_mul(QparT, Rf, tmp); m3_mul(tmp, Q[j], Rnew);
+            m3_vec(QparT, M.joint_pos[d], tj + J_POS);
+            for (int i = 0; i < 9; i++) tj[J_ROT + i] = (float)Rnew[i];
+            tj[J_AXIS] = 1.0f; tj[J_AXIS + 1] = 0.0f; tj[J_AXIS + 2] = 0.0f;
+            tj[J_MASS] = M.body_mass[d];
+            m3_vec(QjT, M.body_com[d], tj + J_COM);
+            {
+                const float *I6 = M.body_inertia[d];
+                double If[9] = {I6[0], I6[1], I6[2], I6[1], I6[3], I6[4], I6[2], I6[4], I6[5]}, T1[9], T2[9];
+                m3_mul(QjT, If, T1); m3_mul(T1, Q[j], T2);
+                tj[J_INERTIA] = (float)T2[0]; tj[J_INERTIA + 1] = (float)T2[1]; tj[J_INERTIA + 2] = (float)T2[2];
+                tj[J_INERTIA + 3] = (float)T2[4]; tj[J_INERTIA + 4] = (float)T2[5]; tj[J_INERTIA + 5] = (float)T2[8];
+            }
             tj[J_LO] = M.dof_lower[d]; tj[J_HI] = M.dof_upper[d]; tj[J_VLIM] = M.dof_vel_limit[d];
             tj[J_ARM] = M.dof_armature[d]; tj[J_DAMP] = M.dof_damping[d];
             tj[J_KP] = P.p_gains[d]; tj[J_KD] = P.d_gains[d]; tj[J_Q0] = P.default_dof_pos[d]; tj[J_TLIM] = P.torque_limits[d];
@@ -1684,10 +1734,13 @@ template <class T> static void fill_limb_table(const lg_params &P, const lg_robo
             float sub = 0.0f;
             for (int jj = j; jj < T::L; jj++) sub += M.body_mass[k * T::L + jj];
             tj[J_SUBM] = sub;
+            for (int i = 0; i < 9; i++) Qpar[i] = Q[j][i];
         }
         for (int i = 0; i < T::NPT; i++) {
             float *tp = tk + T::L * LG_JS + 4 * i;
-            memcpy(tp, M.limb_points[k][i].pos, 12); tp[3] = M.limb_points[k][i].radius;
+            double QjT[9];
+            m3_tr(Q[T::pt_joint(i)], QjT);
+            m3_vec(QjT, M.limb_points[k][i].pos, tp); tp[3] = M.limb_points[k][i].radius;
         }
         for (int g = 0; g < T::NGRP; g++) {        // bounding sphere of each self-collision point group about the midpoint of its two anchor points
             const float *a = M.limb_points[k][T::grp_c0(g)].pos, *b = M.limb_points[k][T::grp_c1(g)].pos;

@@ -27,7 +27,11 @@ from legged_games_gym_amd.utils import get_args
 task = sys.argv[2] if len(sys.argv) > 2 else "anymal_c_flat"
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
 args = get_args(["--task", task, "--num_envs", str(n), "--headless", "--sim_device", "cuda:0", "--rl_device", "cuda:0"])
-env, cfg = task_registry.make_env(task, args)
+env_cfg, _ = task_registry.get_cfgs(task)
+if "nosc" in sys.argv:                      # anymal_c_flat without self-collision (asset.self_collisions = 1)
+    env_cfg.asset.self_collisions = 1
+env, cfg = task_registry.make_env(task, args, env_cfg=env_cfg)
+print("self-collision:", env.self_collision_modelled)
 lib = capi.load_library()
 lib.lg_debug_profile.argtypes, lib.lg_debug_profile.restype = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int], ctypes.c_int
 out = (ctypes.c_uint64 * 20)()
