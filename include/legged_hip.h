@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LG_ABI_VERSION        20
+#define LG_ABI_VERSION        21
 
 #define LG_MAX_LIMBS          4
 #define LG_MAX_CHAIN          6
@@ -108,7 +108,9 @@ typedef struct lg_params {
     int32_t num_reward_slots;
     /* terrain: legged_robot.py:609-637, 831-869; terrain.py */
     int32_t terrain_type, hf_rows, hf_cols, custom_origins;
-    float   hf_horizontal_scale, hf_vertical_scale, hf_border, _padf3;
+    float   hf_horizontal_scale, hf_vertical_scale, hf_border;
+    float   hf_step_threshold;         /* > 0 (mesh_type 'trimesh': slope_treshold x horizontal_scale, legged_robot_config.py:66, terrain.py:69-73): a height
+                                          difference across a cell beyond this [m] is a vertical face at the high side, not a ramp; 0: bilinear patches */
     int32_t terrain_curriculum, terrain_num_rows, terrain_num_cols;
     int32_t self_collision;            /* 1: links of one robot collide with each other (asset.self_collisions == 0, legged_robot.py:683; anymal_c_flat_config.py:42) */
     float   terrain_env_length, max_episode_length_s;

@@ -16,7 +16,7 @@ from typing import Dict, Optional
 
 import numpy as np
 
-LG_ABI_VERSION = 20
+LG_ABI_VERSION = 21
 LG_ADAM_SCRATCH_FLOATS = 2050
 LG_MAX_LIMBS, LG_MAX_CHAIN, LG_MAX_DOF = 4, 6, 12
 LG_MAX_LIMB_POINTS, LG_MAX_BASE_POINTS, LG_MAX_BODIES = 8, 4, 20
@@ -76,7 +76,7 @@ class lg_params(C.Structure):
         ("reward_scale", f32 * LG_NUM_REWARD_TERMS),
         ("only_positive_rewards", i32), ("reward_slot", i32 * LG_NUM_REWARD_TERMS), ("num_reward_slots", i32),
         ("terrain_type", i32), ("hf_rows", i32), ("hf_cols", i32), ("custom_origins", i32),
-        ("hf_horizontal_scale", f32), ("hf_vertical_scale", f32), ("hf_border", f32), ("_padf3", f32),
+        ("hf_horizontal_scale", f32), ("hf_vertical_scale", f32), ("hf_border", f32), ("hf_step_threshold", f32),
         ("terrain_curriculum", i32), ("terrain_num_rows", i32), ("terrain_num_cols", i32), ("self_collision", i32),
         ("terrain_env_length", f32), ("max_episode_length_s", f32),
         ("base_init_state", f32 * 13), ("_padf4", f32),

@@ -119,7 +119,7 @@ enum { PF_PROLOGUE = 0, PF_TORQUE, PF_KINEMATICS, PF_INWARD, PF_BASE, PF_OUTWARD
 
 // ------------------------------------------------------------------ terrain
 // Split in two so the four samples of EVERY collision point of a sub-step are in flight before the first is consumed
-// (the table is L2-resident but ~1 us away for a lone wave): hf_fetch issues the loads, hf_eval does the bilinear patch.
+// (the table is L2-resident but ~1 us away for a lone wave): hf_fetch issues the loads, hf_contact evaluates the patch.
 struct HfFetch { int16_t s00, s10, s01, s11; float tx, ty; };
 template <bool HF> LG_DEV HfFetch hf_fetch(const KArgs &A, float x, float y) {
     HfFetch f; f.s00 = f.s10 = f.s01 = f.s11 = 0; f.tx = f.ty = 0.0f;
@@ -139,18 +139,42 @@ template <bool HF> LG_DEV HfFetch hf_fetch(const KArgs &A, float x, float y) {
     f.s00 = at(ix, iy); f.s10 = at(ix + 1, iy); f.s01 = at(ix, iy + 1); f.s11 = at(ix + 1, iy + 1);
     return f;
 }
-template <bool HF> LG_DEV void hf_eval(const KArgs &A, const HfFetch &f, float &h, V3 &n) {
-    if (!HF) { h = 0.0f; n = v3(0, 0, 1); return; }
+// Ground contact of a collision sphere (centre height pz, radius) from its fetched samples: depth and unit normal.  Twin of the
+// oracle's ground_contact(): bilinear patch; with hf_step_threshold > 0 ('trimesh') a height difference across the cell beyond
+// the threshold is a vertical face at the high side (horizontal normal) and the low level extends up to it.
+template <bool HF> LG_DEV void hf_contact(const KArgs &A, const HfFetch &f, float pz, float radius, float &depth, V3 &n) {
+    if (!HF) { n = v3(0, 0, 1); depth = radius - pz; return; }
     const lg_params &P = A.P;
     float inv = 1.0f / P.hf_horizontal_scale;
     float h00 = (float)f.s00 * P.hf_vertical_scale, h10 = (float)f.s10 * P.hf_vertical_scale;
     float h01 = (float)f.s01 * P.hf_vertical_scale, h11 = (float)f.s11 * P.hf_vertical_scale;
+    const float thr = P.hf_step_threshold;
+    float wall_depth = -1e30f; V3 wall_n = v3(0, 0, 1);
+    if (thr > 0.0f) {                                     // wave-uniform
+        const float hs = P.hf_horizontal_scale;
+        if (fmaxf(fabsf(h10 - h00), fabsf(h11 - h01)) > thr) {
+            const bool up = (h10 + h11) > (h00 + h01);
+            const float top = up ? h10 + (h11 - h10) * f.ty : h00 + (h01 - h00) * f.ty;
+            const float dist = (up ? 1.0f - f.tx : f.tx) * hs;
+            if (pz - radius < top) { float d = radius - dist; if (d > wall_depth) { wall_depth = d; wall_n = v3(up ? -1.0f : 1.0f, 0, 0); } }
+            if (up) { h10 = h00; h11 = h01; } else { h00 = h10; h01 = h11; }
+        }
+        if (fmaxf(fabsf(h01 - h00), fabsf(h11 - h10)) > thr) {
+            const bool up = (h01 + h11) > (h00 + h10);
+            const float top = up ? h01 + (h11 - h01) * f.tx : h00 + (h10 - h00) * f.tx;
+            const float dist = (up ? 1.0f - f.ty : f.ty) * hs;
+            if (pz - radius < top) { float d = radius - dist; if (d > wall_depth) { wall_depth = d; wall_n = v3(0, up ? -1.0f : 1.0f, 0); } }
+            if (up) { h01 = h00; h11 = h10; } else { h00 = h01; h10 = h11; }
+        }
+    }
     float hx0 = h00 + (h10 - h00) * f.tx, hx1 = h01 + (h11 - h01) * f.tx;
-    h = hx0 + (hx1 - hx0) * f.ty;
+    float h = hx0 + (hx1 - hx0) * f.ty;
     float dhdx = ((h10 - h00) + ((h11 - h01) - (h10 - h00)) * f.ty) * inv;
     float dhdy = (hx1 - hx0) * inv;
     float l = 1.0f / sqrtf(dhdx * dhdx + dhdy * dhdy + 1.0f);
     n = v3(-dhdx * l, -dhdy * l, l);
+    depth = radius - (pz - h) * n.z;
+    if (wall_depth > depth) { depth = wall_depth; n = wall_n; }
 }
 // ------------------------------------------------------------------ one 5 ms rigid-body step for (env, limb)
 struct Contact { V3 r, n, vc, f, fs; float depth, bt, vtn; bool on; };   // fs: constant sliding force of the corrector pass
@@ -575,14 +599,14 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, int lane_k, float 
         }
     }
     {   // the samples have had the whole kinematics pass to arrive
-        float h; V3 n;
-        hf_eval<HF>(A, fb, h, n);
-        contact_setup(cb, P, mu, cb.r, n, cb.depth - (root[2] + cb.r.z - h) * n.z, cb.vc, v3(Fbase[0], Fbase[1], Fbase[2]));
+        float dep; V3 n;
+        hf_contact<HF>(A, fb, root[2] + cb.r.z, cb.depth, dep, n);
+        contact_setup(cb, P, mu, cb.r, n, dep, cb.vc, v3(Fbase[0], Fbase[1], Fbase[2]));
         cb.on = cb.on && (lane_k < A.base.num_pts);
 #pragma unroll
         for (int i = 0; i < NPT; i++) {
-            hf_eval<HF>(A, fl[i], h, n);
-            contact_setup(cl[i], P, mu, cl[i].r, n, cl[i].depth - (cl[i].vtn - h) * n.z, cl[i].vc,
+            hf_contact<HF>(A, fl[i], cl[i].vtn, cl[i].depth, dep, n);
+            contact_setup(cl[i], P, mu, cl[i].r, n, dep, cl[i].vc,
                           v3(Frep[T::pt_rep(i)][0], Frep[T::pt_rep(i)][1], Frep[T::pt_rep(i)][2]));
         }
     }

@@ -141,6 +141,10 @@ def build_params(cfg, model, sim_dt: float, num_envs: int, seed: int, gravity=(0
         p.hf_rows, p.hf_cols = terrain.tot_rows, terrain.tot_cols
         p.hf_horizontal_scale, p.hf_vertical_scale = cfg.terrain.horizontal_scale, cfg.terrain.vertical_scale
         p.hf_border = cfg.terrain.border_size
+        # 'trimesh': the reference corrects slopes above slope_treshold to vertical faces when it triangulates the samples
+        # (terrain.py:69-73, legged_robot_config.py:66); 'heightfield' collides against the plain (bilinear) samples
+        thr = getattr(cfg.terrain, "slope_treshold", None)
+        p.hf_step_threshold = float(thr) * cfg.terrain.horizontal_scale if (mesh == "trimesh" and thr is not None) else 0.0
         p.custom_origins = 1
         p.terrain_curriculum = int(bool(cfg.terrain.curriculum))
         p.terrain_num_rows, p.terrain_num_cols = cfg.terrain.num_rows, cfg.terrain.num_cols

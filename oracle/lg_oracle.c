@@ -237,12 +237,15 @@ static inline float hf_at(const lgo_sim *s, int ix, int iy) {
     if (iy > s->P.hf_cols - 1) iy = s->P.hf_cols - 1;
     return (float)s->B.height_samples[(size_t)ix * s->P.hf_cols + iy] * s->P.hf_vertical_scale;
 }
-/* Ground height and unit normal under world point (x,y).  Plane: z=0.
- * Height field: bilinear patch of the 4 surrounding samples (the collision
- * surface of the built-in engine; the reference hands the same int16 grid to
- * PhysX, legged_robot.py:619-637). */
-static void ground_query(const lgo_sim *s, float x, float y, float *h, v3 *n) {
-    if (s->P.terrain_type == LG_TERRAIN_PLANE || !s->B.height_samples) { *h = 0.0f; *n = V(0, 0, 1); return; }
+/* Ground contact of a collision sphere (centre at world (x, y, pz), radius): penetration depth and unit normal.  Plane: z = 0.
+ * Height field: bilinear patch of the 4 surrounding samples (the collision surface of the built-in engine; the reference
+ * hands the same int16 grid to PhysX, legged_robot.py:619-637).
+ * hf_step_threshold > 0 ('trimesh', terrain.py:69-73: slopes above slope_treshold are "corrected to vertical surfaces" when the
+ * samples are triangulated): along an axis whose height difference across the cell exceeds the threshold, the ramp is replaced
+ * by the LOW side's level up to a vertical face at the HIGH side of the cell; a sphere below the top of that face and within
+ * reach of it touches the face with a horizontal normal.  The deepest of {ground, x-face, y-face} is the point's contact. */
+static void ground_contact(const lgo_sim *s, float x, float y, float pz, float radius, float *depth, v3 *n) {
+    if (s->P.terrain_type == LG_TERRAIN_PLANE || !s->B.height_samples) { *n = V(0, 0, 1); *depth = radius - pz; return; }
     float inv = 1.0f / s->P.hf_horizontal_scale;
     float gx = (x + s->P.hf_border) * inv, gy = (y + s->P.hf_border) * inv;
     if (!(fabsf(gx) < 1e9f)) gx = 0.0f;            /* non-finite / absurd position: keep float -> int defined (the env resets) */
@@ -251,12 +254,34 @@ static void ground_query(const lgo_sim *s, float x, float y, float *h, v3 *n) {
     int ix = (int)fx, iy = (int)fy;
     float tx = gx - fx, ty = gy - fy;
     float h00 = hf_at(s, ix, iy), h10 = hf_at(s, ix + 1, iy), h01 = hf_at(s, ix, iy + 1), h11 = hf_at(s, ix + 1, iy + 1);
+    const float thr = s->P.hf_step_threshold;
+    float wall_depth = -1e30f; v3 wall_n = V(0, 0, 1);
+    if (thr > 0.0f) {
+        const float hs = s->P.hf_horizontal_scale;
+        /* x axis: step if either edge along x jumps by more than the threshold; "up" towards the side with the larger sum */
+        if (fmaxf(fabsf(h10 - h00), fabsf(h11 - h01)) > thr) {
+            const int up = (h10 + h11) > (h00 + h01);              /* rising towards +x */
+            const float top = up ? h10 + (h11 - h10) * ty : h00 + (h01 - h00) * ty;       /* level behind the face (y-interpolated) */
+            const float dist = (up ? 1.0f - tx : tx) * hs;         /* horizontal distance to the face */
+            if (pz - radius < top) { float d = radius - dist; if (d > wall_depth) { wall_depth = d; wall_n = V(up ? -1.0f : 1.0f, 0, 0); } }
+            if (up) { h10 = h00; h11 = h01; } else { h00 = h10; h01 = h11; }          /* the low level extends to the face */
+        }
+        if (fmaxf(fabsf(h01 - h00), fabsf(h11 - h10)) > thr) {
+            const int up = (h01 + h11) > (h00 + h10);
+            const float top = up ? h01 + (h11 - h01) * tx : h00 + (h10 - h00) * tx;
+            const float dist = (up ? 1.0f - ty : ty) * hs;
+            if (pz - radius < top) { float d = radius - dist; if (d > wall_depth) { wall_depth = d; wall_n = V(0, up ? -1.0f : 1.0f, 0); } }
+            if (up) { h01 = h00; h11 = h10; } else { h00 = h01; h10 = h11; }
+        }
+    }
     float hx0 = h00 + (h10 - h00) * tx, hx1 = h01 + (h11 - h01) * tx;
-    *h = hx0 + (hx1 - hx0) * ty;
+    float h = hx0 + (hx1 - hx0) * ty;
     float dhdx = ((h10 - h00) + ((h11 - h01) - (h10 - h00)) * ty) * inv;
     float dhdy = (hx1 - hx0) * inv;
     float l = 1.0f / sqrtf(dhdx * dhdx + dhdy * dhdy + 1.0f);
     *n = V(-dhdx * l, -dhdy * l, l);
+    *depth = radius - (pz - h) * n->z;
+    if (wall_depth > *depth) { *depth = wall_depth; *n = wall_n; }
 }
 
 /* Torque a drive can still deliver at joint speed qd: fades linearly to zero over the last 10 % below the URDF velocity
@@ -528,9 +553,7 @@ static void physics_substep_env(const lgo_sim *s, int e, const float *tau, int w
             c->body = b; c->report = pt->report_body;
             c->r = mv(Rb[b], V(pt->pos[0], pt->pos[1], pt->pos[2]));
             v3 pw = add(rb[b], c->r);
-            float h;
-            ground_query(s, root[0] + pw.x, root[1] + pw.y, &h, &c->n);
-            c->depth = pt->radius - (root[2] + pw.z - h) * c->n.z;
+            ground_contact(s, root[0] + pw.x, root[1] + pw.y, root[2] + pw.z, pt->radius, &c->depth, &c->n);
             c->on = c->depth > -P->contact_margin;
             c->vc = add(vb[b], cross(wb[b], c->r));
             c->kn = P->contact_stiffness * dt + P->contact_damping;

@@ -213,3 +213,51 @@ def test_config3_anymal_rough_4096_full_terrain():
     _step_parity_every_env(o, d, N, act, 750, vel_tol=0.1, pos_tol=1e-3, obs_tol=1e-2, rew_tol=1e-3, min_contact_frac=0.8)
     assert np.abs(o.buf["sea_hidden_state"] - _get(d, "sea_hidden_state")).max() < 5e-3
     _invariants(d, N, robot, dm, steps=200, action_std=1.0, vel_limit=20.0, first_step=751, upright_frac=0.3)
+
+
+def test_trimesh_vertical_faces_parity():
+    """mesh_type 'trimesh' (the registered anymal_c_rough / cassie default): stair risers and obstacle edges beyond slope_treshold are
+    vertical faces (hf_step_threshold).  (i) the riser scenario of tests/test_oracle_physics.py, HIP against oracle, with the
+    _reward_stumble condition on the front feet; (ii) 1000 envs on curriculum stairs / obstacles, settled, one policy step."""
+    from tests.test_oracle_physics import _riser_setup, riser_state
+    from oracle.oracle import OracleSim
+    from legged_games_gym_amd.device_sim import DeviceSim
+    terr, cfg, robot, p, names, model, w, x_face = _riser_setup("trimesh", N=64)
+    N = 64
+    o = OracleSim(p, model, robot, w)
+    o.set_terrain(terr.heightsamples, terr.env_origins)
+    d = DeviceSim(p, model, robot, torch.device("cuda:0"), w, terr.heightsamples, terr.env_origins)
+    riser_state(o, p, robot, N, x_face)
+    rng = np.random.default_rng(0)
+    o.buf["root_states"][:, 0] += rng.uniform(-0.03, 0.02, N).astype(np.float32)      # from 2 cm clear of the face to 4 cm inside
+    for k in ("root_states", "dof_state", "contact_forces", "env_origins"):
+        d.buf[k].copy_(torch.from_numpy(o.buf[k]).view(d.buf[k].shape))
+    tau = rng.normal(0, 5.0, (N, 12)).astype(np.float32)
+    o.physics_substep(tau, True); d.physics_substep(torch.from_numpy(tau), True)
+    cf_o, cf_d = o.buf["contact_forces"], _get(d, "contact_forces")
+    feet = robot.bodies_matching("FOOT")
+    stum_o = np.linalg.norm(cf_o[:, feet, :2], axis=-1) > 5.0 * np.abs(cf_o[:, feet, 2])
+    stum_d = np.linalg.norm(cf_d[:, feet, :2], axis=-1) > 5.0 * np.abs(cf_d[:, feet, 2])
+    assert stum_o[:, [0, 2]].any(axis=1).mean() > 0.3 and np.array_equal(stum_o, stum_d)          # LF / RF against the riser
+    assert np.abs(cf_o - cf_d).max() < 2e-3 * max(1.0, np.abs(cf_o).max())
+    assert np.abs(o.buf["dof_state"] - _get(d, "dof_state")).max() < 2e-3 and np.abs(o.buf["root_states"] - _get(d, "root_states")).max() < 1e-3
+    # (ii) curriculum terrain with stairs / discrete obstacles
+    from tests.test_gpu_parity import _rough_terrain
+    N = 1000
+    terr = _rough_terrain(N)
+
+    def tweak(cfg):
+        cfg.terrain.mesh_type, cfg.terrain.num_rows, cfg.terrain.num_cols, cfg.terrain.border_size = "trimesh", 4, 5, 5
+        cfg.terrain.max_init_terrain_level = 3
+    cfg, robot, p, names, model, w = make_setup("anymal_c_rough", N, tweak=tweak, terrain=terr, plane=False)
+    assert p.hf_step_threshold > 0
+    o = OracleSim(p, model, robot, w, threads=16)
+    d = DeviceSim(p, model, robot, torch.device("cuda:0"), w)
+    o.set_terrain(terr.heightsamples, terr.env_origins); d.set_terrain(terr.heightsamples, terr.env_origins)
+    _spawn(d, N, terr, cfg, np.random.default_rng(0), (0.5, 1.25), (-5.0, 5.0))
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for it in range(1, 41):                              # wander a little so that feet meet risers
+        d.step(torch.randn(N, 12, device="cuda", generator=g) * 0.5, it)
+    _device_to_oracle(d, o)
+    act = (torch.randn(N, 12, generator=torch.Generator().manual_seed(1)) * 0.3).float()
+    _step_parity_every_env(o, d, N, act, 41, vel_tol=0.1, pos_tol=1e-3, obs_tol=1e-2, rew_tol=1e-3, min_contact_frac=0.7)
