@@ -55,6 +55,7 @@ def parse_args():
     ap.add_argument("--no-fused-step", action="store_true", help="keep actor kernel and step kernel separate (lg_policy_act + lg_step)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one captured HIP graph per step")
     ap.add_argument("--training-iters", type=int, default=-1, help="PPO iterations timed for the ppo_training object (0 = skip; -1 = 100 for anymal_c_flat, 20 otherwise)")
+    ap.add_argument("--trimesh", action="store_true", help="keep the registered mesh_type 'trimesh' (vertical faces beyond slope_treshold) instead of BASELINE.json's height-field contact")
     ap.add_argument("--min-timed-ms", type=float, default=50.0, help="a timed region shorter than this is repeated and the median reported")
     ap.add_argument("--event-steps", type=int, default=200, help="steps timed with HIP events for the step-kernel-only graph (tasks whose timed graph also holds the actor kernel)")
     return ap.parse_args()
@@ -152,8 +153,12 @@ def worker(a):
                      "--rl_device", f"cuda:{local_rank}"])
     env_cfg, train_cfg = task_registry.get_cfgs(a.task)
     env_cfg.seed = train_cfg.seed + rank                  # rank-local RNG stream
+    mesh_registered = env_cfg.terrain.mesh_type
+    if mesh_registered == "trimesh" and not a.trimesh:    # BASELINE.json configs 3-5 name HEIGHT-FIELD contact
+        env_cfg.terrain.mesh_type = "heightfield"
     with contextlib.redirect_stdout(io.StringIO()):
         env, _ = task_registry.make_env(a.task, args, env_cfg=env_cfg)
+    env_cfg.terrain.mesh_type = mesh_registered           # (the registry hands out its one cfg object: leave it as registered)
     env.set_fixed_commands(0.5, 0.0, 0.0)                 # "fixed command" of BASELINE.json
     torch.manual_seed(train_cfg.seed)                     # random-init policy, same on every rank
     pol = class_to_dict(train_cfg.policy)

@@ -238,6 +238,39 @@ class PPO:
             g.copy_(flat[o:o + g.numel()].view_as(g))
             o += g.numel()
 
+    def _flat_grad_views(self):
+        """Data-parallel kernel path: every parameter's ``.grad`` (and the policy-std gradient the loss kernel writes) becomes a
+        view of ONE persistent flat buffer, with one extra slot for the mean KL.  The learner kernels then write their gradients
+        straight into that buffer and a mini-batch step needs a single all-reduce over it (RCCL: one collective of
+        n_params + 1 floats instead of a concatenation, an all-reduce, a scalar all-reduce and 17 copies back)."""
+        params = list(self.actor_critic.parameters())
+        n = sum(p.numel() for p in params)
+        buf = getattr(self, "_gflat", None)
+        if buf is None or buf.numel() != n + 1 or any(p.grad is None or p.grad.data_ptr() != buf[o].data_ptr() for p, o in zip(params, self._goffs)):
+            buf = torch.zeros(n + 1, device=self.device)
+            offs, o = [], 0
+            for p in params:
+                if p.grad is not None:
+                    buf[o:o + p.numel()].copy_(p.grad.reshape(-1))
+                p.grad = buf[o:o + p.numel()].view_as(p)
+                offs.append(o)
+                o += p.numel()
+            self._gflat, self._goffs = buf, offs
+            std = self.actor_critic.std
+            self._d_std = std.grad                      # the loss kernels write d loss / d std here
+            self._mlp = None                            # descriptors hold the old .grad addresses
+        return self._gflat
+
+    def _allreduce_flat(self, adaptive):
+        """One collective per mini-batch step: mean gradient and (adaptive schedule) mean KL over the ranks."""
+        flat = self._gflat
+        if adaptive:
+            flat[-1:].copy_(self._stats[2:3])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.mul_(1.0 / _world())
+        if adaptive:
+            self._stats[2:3].copy_(flat[-1:])
+
     def after_optimizer_load(self):
         """The optimiser's tensors were replaced (checkpoint resume): re-link the device learning rate, drop the captured graph."""
         if self._graph_ok:
@@ -326,7 +359,10 @@ class PPO:
         mb, A = mu.shape
         if getattr(self, "_d_mu", None) is None or self._d_mu.shape != mu.shape:
             self._d_mu, self._d_val = torch.empty_like(mu), torch.empty(mb, 1, device=mu.device)
-            self._d_std, self._stats = torch.zeros(A, device=mu.device), torch.zeros(4, device=mu.device)
+            if getattr(self, "_d_std", None) is None or self._d_std.numel() != A:
+                self._d_std = torch.zeros(A, device=mu.device)
+            if getattr(self, "_stats", None) is None:
+                self._stats = torch.zeros(4, device=mu.device)
         d_mu, d_val = (tr.grad_outputs if tr is not None else (self._d_mu, self._d_val))
         p = lambda t: t.data_ptr()
         rc = self._lib.lg_ppo_loss(p(mu), p(ac.std), p(val), p(ix), p(st.actions), p(st.actions_log_prob), p(st.mu), p(st.sigma), p(st.advantages),
@@ -345,13 +381,19 @@ class PPO:
         The bracket is ONE kernel (lg_ppo_minibatch) when the networks have the learner kernels' shape; otherwise torch MLP
         passes (autograd) around lg_ppo_loss."""
         st, ac, ix = self.storage, self.actor_critic, self._ix
+        flat_dp = _world() > 1 and self._mlp_kernels
+        if flat_dp:
+            self._flat_grad_views()                  # .grad tensors = views of one buffer (before the descriptors read their addresses)
         tr = self._mlp_trainer()
+        flat_dp = flat_dp and tr is not None         # (torch MLP path: autograd allocates its own .grad tensors)
         p = lambda t: t.data_ptr()
         if tr is not None and self._fused_minibatch:
             # forward + loss + backward of both networks in ONE kernel (lg_ppo_minibatch): mu / value never reach HBM
             mb, A = ix.numel(), ac.std.numel()
             if getattr(self, "_d_std", None) is None or self._d_std.numel() != A:
-                self._d_std, self._stats = torch.zeros(A, device=self.device), torch.zeros(4, device=self.device)
+                self._d_std = torch.zeros(A, device=self.device)
+            if getattr(self, "_stats", None) is None:
+                self._stats = torch.zeros(4, device=self.device)
             tr.refresh()
             from .. import capi
             b = capi.lg_ppo_batch()
@@ -367,7 +409,9 @@ class PPO:
             acc_done = False
         ac.std.grad = self._d_std
         adaptive = self.desired_kl is not None and self.schedule == "adaptive"
-        if _world() > 1:                             # data-parallel ranks: mean gradient and mean KL (rollout shards are equal-sized)
+        if flat_dp:                                  # data-parallel ranks: mean gradient and mean KL (rollout shards are equal-sized), ONE collective
+            self._allreduce_flat(adaptive)
+        elif _world() > 1:
             self._allreduce_grads()
             if adaptive:
                 dist.all_reduce(self._stats[2:3], op=dist.ReduceOp.SUM)

@@ -321,3 +321,60 @@ def test_kernel_update_with_fixed_schedule_keeps_the_learning_rate():
     assert all(float(st_["step"]) == 3 * 8 for st_ in alg.optimizer.state.values())
     assert all(not torch.equal(a, b) for a, b in zip(before, ac.parameters()))
     assert all(bool(torch.isfinite(p).all()) for p in ac.parameters())
+
+
+def _dp_worker(rank, world, port, out):
+    """One data-parallel rank of the KERNEL update (learner kernels + lg_adam_step, one flat all-reduce per mini-batch step) on the
+    shared test GPU; gloo stands in for RCCL (two ranks cannot share one device under RCCL)."""
+    import os
+    import torch.distributed as dist
+    from legged_games_gym_amd.rl import ActorCritic, PPO
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    torch.manual_seed(0)
+    ac = ActorCritic(48, 48, 12, actor_hidden_dims=[128, 64, 32], critic_hidden_dims=[128, 64, 32])
+    alg = PPO(ac, num_learning_epochs=1, num_mini_batches=1, schedule="adaptive", desired_kl=0.01, learning_rate=1e-3, entropy_coef=0.01, device="cuda:0")
+    T, N = 8, 256
+    alg.init_storage(N, T, [48], [None], [12])
+    snaps = []
+    for it in range(4):
+        _storage(T=T, N=N, seed=100 * it + rank, st=alg.storage)
+        alg.storage.compute_returns(torch.zeros(N, 1, device="cuda"), 0.99, 0.95)
+        perm = torch.randperm(T * N, device="cuda", generator=torch.Generator(device="cuda").manual_seed(it))
+        alg.update(perm=perm)
+        snaps.append([p.detach().cpu().clone() for p in alg.actor_critic.parameters()] + [torch.tensor(alg.learning_rate)])
+    used_flat = getattr(alg, "_gflat", None) is not None and alg._mlp is not None
+    torch.save({"snaps": snaps, "flat": used_flat}, f"{out}/r{rank}.pt")
+    dist.destroy_process_group()
+
+
+def test_data_parallel_kernel_update_two_ranks_one_gpu(tmp_path):
+    """the N > 1 update on the kernel path.  Two gloo ranks on the one GPU: (i) replicas stay BIT-identical over 4
+    updates (the gradients come out of one all-reduced flat buffer on both), (ii) the first update equals the single-process update on
+    the concatenated batch (mean of the two shards' gradients and KLs, global advantage normalisation through the all-gather)."""
+    import socket
+    import torch.multiprocessing as mp
+    from legged_games_gym_amd.rl import ActorCritic, PPO
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "r0.pt", weights_only=True); r1 = torch.load(tmp_path / "r1.pt", weights_only=True)
+    assert r0["flat"] and r1["flat"]                                     # the kernel path with the flat gradient buffer was the one that ran
+    for a, b in zip(r0["snaps"], r1["snaps"]):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    # single process, both shards as one batch of 512 envs (first update only: later ones start from different storages per rank)
+    torch.manual_seed(0)
+    ac = ActorCritic(48, 48, 12, actor_hidden_dims=[128, 64, 32], critic_hidden_dims=[128, 64, 32])
+    alg = PPO(ac, num_learning_epochs=1, num_mini_batches=1, schedule="adaptive", desired_kl=0.01, learning_rate=1e-3, entropy_coef=0.01, device="cuda:0")
+    T, N = 8, 256
+    alg.init_storage(2 * N, T, [48], [None], [12])
+    a, b = _storage(T=T, N=N, seed=0), _storage(T=T, N=N, seed=1)
+    for name in ("observations", "actions", "rewards", "dones", "values", "actions_log_prob", "mu", "sigma"):
+        getattr(alg.storage, name).copy_(torch.cat((getattr(a, name), getattr(b, name)), dim=1))
+    alg.storage.step = T
+    alg.storage.compute_returns(torch.zeros(2 * N, 1, device="cuda"), 0.99, 0.95)
+    alg.update()
+    for want, got in zip(alg.actor_critic.parameters(), r0["snaps"][0]):
+        assert torch.allclose(want.detach().cpu(), got, rtol=2e-4, atol=2e-6), float((want.detach().cpu() - got).abs().max())
+    assert abs(alg.learning_rate - float(r0["snaps"][0][-1])) < 1e-9
