@@ -253,6 +253,16 @@ size_t lg_mlp_workspace_bytes(const lg_mlp_net *nets, int32_t n_nets);
 int  lg_mlp_backward(const lg_mlp_net *nets, int32_t n_nets, const int64_t *rows, int32_t mb, float *workspace, size_t workspace_bytes,
                      void *stream);
 
+/* The same two passes for MLPs of ANY widths (the 512-256-128 networks of anymal_c_rough / cassie / a1 / anymal_b, reference
+ * legged_robot_config.py:205-208): every layer is a tiled f32-MFMA GEMM with bias / ELU / ELU' fused into its epilogue
+ * (csrc/lg_gemm.h).  The activations of the forward pass stay in `workspace` (lg_mlp_wide_workspace_bytes(nets, n_nets, mb)
+ * bytes) for the backward pass that follows; weight gradients are summed in a fixed order (bit-reproducible). */
+size_t lg_mlp_wide_workspace_bytes(const lg_mlp_net *nets, int32_t n_nets, int32_t mb);
+int  lg_mlp_wide_forward(const lg_mlp_net *nets, int32_t n_nets, const int64_t *rows, int32_t mb, float *workspace, size_t workspace_bytes,
+                         void *stream);
+int  lg_mlp_wide_backward(const lg_mlp_net *nets, int32_t n_nets, const int64_t *rows, int32_t mb, float *workspace, size_t workspace_bytes,
+                          void *stream);
+
 /* What one PPO mini-batch step reads besides the observations (rsl_rl PPO.update [EXTERNAL]; hyper-parameters
  * legged_robot_config.py:215-228): the rollout storage (flattened [B, .] device arrays, gathered through `rows`), the policy's std
  * parameter and the loss coefficients; and what it produces besides the network gradients. */

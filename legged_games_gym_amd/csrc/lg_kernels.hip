@@ -19,6 +19,7 @@
 #include "lg_device.h"
 #include "lg_policy.h"
 #include "lg_train.h"
+#include "lg_gemm.h"
 
 using namespace lg;
 
@@ -2017,6 +2018,137 @@ int lg_ppo_minibatch(const lg_mlp_net *nets, const int64_t *rows, int32_t mb, co
     if (!batch) return fail(-1, "null batch");
     return mlp_backward_launch(nets, 2, rows, mb, batch, workspace, workspace_bytes, stream);
 }
+
+// ---- learner kernels for the wide MLPs (lg_gemm.h): per layer a tiled f32-MFMA GEMM with the element-wise work in its epilogue
+struct WideLayout { size_t x[4], g[4], part, total; int splits[4]; int kchunk[4]; };      // float offsets into one net's workspace slice
+static void wide_layout(const lg_mlp_net &n, int mb, WideLayout &L) {
+    size_t o = 0;
+    for (int l = 1; l <= 3; l++) { L.x[l] = o; o += (size_t)mb * n.dims[l]; }
+    for (int l = 1; l <= 3; l++) { L.g[l] = o; o += (size_t)mb * n.dims[l]; }
+    size_t pmax = 0;
+    for (int l = 0; l < 4; l++) {
+        const int tiles = ((n.dims[l + 1] + LG_GT - 1) / LG_GT) * ((n.dims[l] + 1 + LG_GT - 1) / LG_GT);
+        int sp = (384 + tiles - 1) / tiles;                                   // enough workgroups for the chip: tiles x splits >= ~1.5 x CUs
+        if (sp > LG_WIDE_MAX_SPLITS) sp = LG_WIDE_MAX_SPLITS;
+        int chunk = (mb + sp - 1) / sp;
+        chunk = ((chunk + LG_GK - 1) / LG_GK) * LG_GK;
+        if (chunk < LG_GK) chunk = LG_GK;
+        sp = (mb + chunk - 1) / chunk;
+        L.splits[l] = sp; L.kchunk[l] = chunk;
+        const size_t p = (size_t)sp * n.dims[l + 1] * (n.dims[l] + 1);
+        if (p > pmax) pmax = p;
+    }
+    L.part = o; o += pmax;
+    L.total = (o + 3) & ~(size_t)3;
+}
+static int wide_check(const lg_mlp_net *nets, int32_t n_nets, int32_t mb) {
+    if (!nets || n_nets < 1 || n_nets > 2 || mb <= 0) return fail(-1, "bad argument");
+    for (int n = 0; n < n_nets; n++) {
+        for (int l = 0; l <= 4; l++) if (nets[n].dims[l] <= 0 || nets[n].dims[l] > 4096) return fail(-4, "lg_mlp_wide_*: layer widths must be in 1..4096");
+        for (int l = 0; l < 4; l++) if (!nets[n].weights[l] || !nets[n].biases[l]) return fail(-1, "null layer pointer");
+        if (!nets[n].input) return fail(-1, "null input");
+    }
+    return 0;
+}
+
+extern "C" {
+
+size_t lg_mlp_wide_workspace_bytes(const lg_mlp_net *nets, int32_t n_nets, int32_t mb) {
+    if (!nets || mb <= 0) return 0;
+    size_t total = 0;
+    for (int n = 0; n < n_nets; n++) { WideLayout L; wide_layout(nets[n], mb, L); total += L.total; }
+    return total * sizeof(float);
+}
+
+int lg_mlp_wide_forward(const lg_mlp_net *nets, int32_t n_nets, const int64_t *rows, int32_t mb, float *workspace, size_t workspace_bytes, void *stream) {
+    if (int rc = wide_check(nets, n_nets, mb)) return rc;
+    if (!workspace || workspace_bytes < lg_mlp_wide_workspace_bytes(nets, n_nets, mb)) return fail(-1, "workspace too small (lg_mlp_wide_workspace_bytes)");
+    for (int n = 0; n < n_nets; n++) if (!nets[n].output) return fail(-1, "null output");
+    hipStream_t st = (hipStream_t)stream;
+    for (int l = 0; l < 4; l++) {
+        lg::GemmArgs a; memset(&a, 0, sizeof a);
+        a.rows = rows; a.gather_a_rows = (l == 0 && rows) ? 1 : 0; a.mb = mb;
+        int gx = 0, gy = 0;
+        float *ws = workspace;
+        for (int n = 0; n < n_nets; n++) {
+            WideLayout L; wide_layout(nets[n], mb, L);
+            lg::GemmNet &g = a.net[n];
+            const int32_t *d = nets[n].dims;
+            g.A = l == 0 ? nets[n].input : ws + L.x[l]; g.lda = d[l];
+            g.B = nets[n].weights[l]; g.ldb = d[l]; g.bias = nets[n].biases[l];
+            g.C = l == 3 ? nets[n].output : ws + L.x[l + 1]; g.ldc = d[l + 1];
+            g.M = mb; g.N = d[l + 1]; g.K = d[l]; g.elu = l < 3; g.splits = 1; g.k_chunk = g.K; g.ones_col = -1;
+            g.tiles_m = (g.M + LG_GT - 1) / LG_GT; g.tiles_n = (g.N + LG_GT - 1) / LG_GT;
+            if (g.tiles_m > gx) gx = g.tiles_m;
+            if (g.tiles_n > gy) gy = g.tiles_n;
+            ws += L.total;
+        }
+        hipLaunchKernelGGL((lg::k_gemm_wide<lg::GEMM_FWD>), dim3(gx, gy, n_nets), dim3(256), 0, st, a);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+/* Gradients of all weights / biases given dL/d output (nets[n].grad_output); uses the activations the preceding
+ * lg_mlp_wide_forward left in the same workspace. */
+int lg_mlp_wide_backward(const lg_mlp_net *nets, int32_t n_nets, const int64_t *rows, int32_t mb, float *workspace, size_t workspace_bytes, void *stream) {
+    if (int rc = wide_check(nets, n_nets, mb)) return rc;
+    if (!workspace || workspace_bytes < lg_mlp_wide_workspace_bytes(nets, n_nets, mb)) return fail(-1, "workspace too small (lg_mlp_wide_workspace_bytes)");
+    for (int n = 0; n < n_nets; n++) {
+        if (!nets[n].grad_output) return fail(-1, "null grad_output");
+        for (int l = 0; l < 4; l++) if (!nets[n].grad_weights[l] || !nets[n].grad_biases[l]) return fail(-1, "null gradient pointer");
+    }
+    hipStream_t st = (hipStream_t)stream;
+    for (int l = 3; l >= 0; l--) {
+        // dW_l, db_l (split over the mini-batch rows) ...
+        lg::GemmArgs a; memset(&a, 0, sizeof a);
+        lg::WideReduceArgs r; memset(&r, 0, sizeof r);
+        a.rows = rows; a.gather_b_k = (l == 0 && rows) ? 1 : 0; a.mb = mb;
+        int gx = 0, gy = 0, rmax = 0;
+        float *ws = workspace;
+        for (int n = 0; n < n_nets; n++) {
+            WideLayout L; wide_layout(nets[n], mb, L);
+            lg::GemmNet &g = a.net[n];
+            const int32_t *d = nets[n].dims;
+            g.A = l == 3 ? nets[n].grad_output : ws + L.g[l + 1]; g.lda = d[l + 1];
+            g.B = l == 0 ? nets[n].input : ws + L.x[l]; g.ldb = d[l];
+            g.C = ws + L.part; g.ldc = d[l] + 1;
+            g.M = d[l + 1]; g.N = d[l]; g.K = mb; g.splits = L.splits[l]; g.k_chunk = L.kchunk[l]; g.ones_col = d[l];
+            g.tiles_m = (g.M + LG_GT - 1) / LG_GT; g.tiles_n = (d[l] + 1 + LG_GT - 1) / LG_GT;
+            if (g.tiles_m > gx) gx = g.tiles_m;
+            if (g.tiles_n * g.splits > gy) gy = g.tiles_n * g.splits;
+            r.part[n] = ws + L.part; r.gw[n] = nets[n].grad_weights[l]; r.gb[n] = nets[n].grad_biases[l];
+            r.N[n] = d[l + 1]; r.K[n] = d[l]; r.splits[n] = L.splits[l];
+            if (d[l + 1] * (d[l] + 1) > rmax) rmax = d[l + 1] * (d[l] + 1);
+            ws += L.total;
+        }
+        hipLaunchKernelGGL((lg::k_gemm_wide<lg::GEMM_DW>), dim3(gx, gy, n_nets), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(lg::k_wide_reduce, dim3((rmax + 255) / 256, n_nets), dim3(256), 0, st, r);
+        if (l == 0) break;
+        // ... and G_l = (G_{l+1} W_l) * elu'(X_l)
+        lg::GemmArgs b; memset(&b, 0, sizeof b);
+        b.mb = mb;
+        gx = gy = 0; ws = workspace;
+        for (int n = 0; n < n_nets; n++) {
+            WideLayout L; wide_layout(nets[n], mb, L);
+            lg::GemmNet &g = b.net[n];
+            const int32_t *d = nets[n].dims;
+            g.A = l == 3 ? nets[n].grad_output : ws + L.g[l + 1]; g.lda = d[l + 1];
+            g.B = nets[n].weights[l]; g.ldb = d[l];
+            g.C = ws + L.g[l]; g.ldc = d[l]; g.act = ws + L.x[l];
+            g.M = mb; g.N = d[l]; g.K = d[l + 1]; g.splits = 1; g.k_chunk = g.K; g.ones_col = -1;
+            g.tiles_m = (g.M + LG_GT - 1) / LG_GT; g.tiles_n = (g.N + LG_GT - 1) / LG_GT;
+            if (g.tiles_m > gx) gx = g.tiles_m;
+            if (g.tiles_n > gy) gy = g.tiles_n;
+            ws += L.total;
+        }
+        hipLaunchKernelGGL((lg::k_gemm_wide<lg::GEMM_DX>), dim3(gx, gy, n_nets), dim3(256), 0, st, b);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C" (wide MLP entry points; still inside the enclosing block)
 
 int lg_rollout_record(const lg_rollout_step *s, void *stream) {
     if (!s || !s->obs || !s->actions || !s->mean || !s->rewards || !s->dones || !s->storage_obs || !s->storage_actions || !s->storage_mu ||

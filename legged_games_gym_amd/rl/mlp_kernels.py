@@ -18,6 +18,7 @@ def _linears(seq: nn.Sequential) -> List[nn.Linear]:
 
 class MlpTrainer:
     """Forward / backward of up to two ``nn.Sequential`` MLPs (actor, critic) over a mini-batch of storage rows."""
+    has_fused_minibatch = True      # lg_ppo_minibatch: forward + PPO loss + backward in one kernel (48-128-64-32 shape)
 
     def __init__(self, nets: Sequence[nn.Sequential], inputs: Sequence[torch.Tensor], mb: int, forward_only: bool = False):
         self.lib = capi.load_library()
@@ -90,3 +91,43 @@ class MlpTrainer:
         dev = self.inputs[0].device
         self._check(self.lib.lg_ppo_minibatch(self.desc, rows.data_ptr(), self.mb, C.byref(batch), self.workspace.data_ptr(),
                                               self.workspace.numel() * 4, torch.cuda.current_stream(dev).cuda_stream), "lg_ppo_minibatch")
+
+
+class WideMlpTrainer(MlpTrainer):
+    """The same interface for MLPs of any widths (the 512-256-128 networks of the rough tasks): layer-by-layer tiled f32-MFMA GEMMs
+    (lg_mlp_wide_forward / lg_mlp_wide_backward, csrc/lg_gemm.h).  forward() leaves the activations in the workspace, the
+    backward() that follows reads them; there is no single-kernel mini-batch step for these widths (``has_fused_minibatch``)."""
+    has_fused_minibatch = False
+
+    def __init__(self, nets: Sequence[nn.Sequential], inputs: Sequence[torch.Tensor], mb: int, forward_only: bool = False):
+        self.lib = capi.load_library()
+        self.forward_only = forward_only
+        self.nets, self.inputs, self.mb = list(nets), list(inputs), int(mb)
+        self.layers = [_linears(n) for n in self.nets]
+        self.supported = all(len(l) == 4 for l in self.layers) and all(
+            len(n) == 7 and all(isinstance(m, nn.Linear if i % 2 == 0 else nn.ELU) and (i % 2 == 0 or m.alpha == 1.0) for i, m in enumerate(n))
+            for n in self.nets) and all(m.out_features <= 4096 and m.in_features <= 4096 for l in self.layers for m in l)
+        if not self.supported:
+            return
+        dev = self.inputs[0].device
+        self.outputs = [torch.empty(self.mb, l[-1].out_features, device=dev) for l in self.layers]
+        self.grad_outputs = [] if forward_only else [torch.zeros_like(o) for o in self.outputs]
+        self.desc = (capi.lg_mlp_net * len(self.nets))()
+        self.refresh()
+        need = self.lib.lg_mlp_wide_workspace_bytes(self.desc, len(self.nets), self.mb)
+        self.workspace = torch.empty(need // 4 + 4, device=dev)
+
+    def _args(self, rows):
+        dev = self.inputs[0].device
+        return (self.desc, len(self.nets), rows.data_ptr() if rows is not None else None, self.mb, self.workspace.data_ptr(),
+                self.workspace.numel() * 4, torch.cuda.current_stream(dev).cuda_stream)
+
+    def forward(self, rows: Optional[torch.Tensor]):
+        self._check(self.lib.lg_mlp_wide_forward(*self._args(rows)), "lg_mlp_wide_forward")
+        return self.outputs
+
+    def backward(self, rows: Optional[torch.Tensor]):
+        self._check(self.lib.lg_mlp_wide_backward(*self._args(rows)), "lg_mlp_wide_backward")
+
+    def ppo_minibatch(self, rows, batch):
+        raise RuntimeError("no fused mini-batch kernel for the wide MLPs: forward -> lg_ppo_loss -> backward")

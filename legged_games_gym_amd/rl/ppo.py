@@ -170,6 +170,7 @@ class PPO:
         # small torch kernels, updating torch.optim.Adam's own state tensors in place.  LG_PPO_ADAM_KERNEL=0 disables.
         self._adam_kernel = self._fused_loss and _os.environ.get("LG_PPO_ADAM_KERNEL", "1") != "0"
         self._fused_minibatch = _os.environ.get("LG_PPO_FUSED_MINIBATCH", "1") != "0"   # lg_ppo_minibatch instead of forward / loss / backward
+        self._wide_kernels = _os.environ.get("LG_PPO_WIDE_KERNELS", "1") != "0"         # lg_mlp_wide_* for widths the LDS-resident kernels do not cover
         self._split_k = _os.environ.get("LG_PPO_SPLIT_K", "1") != "0"       # torch MLP path (wide networks): see _LinearSplitK
         self._lib = None
         self.desired_kl, self.schedule, self.learning_rate = desired_kl, schedule, learning_rate
@@ -311,7 +312,10 @@ class PPO:
                 self._mlp_kernels = False
                 return None
             self._mlp, self._mlp_key = MlpTrainer([ac.actor, ac.critic], [obs, cobs], mb), key
-            if not self._mlp.supported:
+            if not self._mlp.supported:                  # not the LDS-resident shape: the layer-wise GEMM kernels take any widths
+                from .mlp_kernels import WideMlpTrainer
+                self._mlp = WideMlpTrainer([ac.actor, ac.critic], [obs, cobs], mb) if self._wide_kernels else None
+            if self._mlp is None or not self._mlp.supported:
                 self._mlp_kernels, self._mlp = False, None
                 return None
         return self._mlp
@@ -387,7 +391,7 @@ class PPO:
         tr = self._mlp_trainer()
         flat_dp = flat_dp and tr is not None         # (torch MLP path: autograd allocates its own .grad tensors)
         p = lambda t: t.data_ptr()
-        if tr is not None and self._fused_minibatch:
+        if tr is not None and self._fused_minibatch and tr.has_fused_minibatch:
             # forward + loss + backward of both networks in ONE kernel (lg_ppo_minibatch): mu / value never reach HBM
             mb, A = ix.numel(), ac.std.numel()
             if getattr(self, "_d_std", None) is None or self._d_std.numel() != A:
@@ -512,7 +516,7 @@ class PPO:
             # Capture.  On the kernel path a mini-batch step is 5 launches, so all epochs x mini-batches go into ONE graph (each
             # step reading its own slice of _perm_buf); the torch MLP path (~150 launches and fresh activations per step) keeps a
             # one-step graph replayed 20 times.
-            self._graph_whole = self._mlp is not None and self._fused_minibatch and self._adam_kernel
+            self._graph_whole = self._mlp is not None and self._adam_kernel and (not self._mlp.has_fused_minibatch or self._fused_minibatch)
             self._gstream.wait_stream(cur)
             self._zero_grad()
             g = torch.cuda.CUDAGraph()

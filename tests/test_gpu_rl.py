@@ -378,3 +378,55 @@ def test_data_parallel_kernel_update_two_ranks_one_gpu(tmp_path):
     for want, got in zip(alg.actor_critic.parameters(), r0["snaps"][0]):
         assert torch.allclose(want.detach().cpu(), got, rtol=2e-4, atol=2e-6), float((want.detach().cpu() - got).abs().max())
     assert abs(alg.learning_rate - float(r0["snaps"][0][-1])) < 1e-9
+
+
+def _wide_mlp(i, o, seed):
+    import torch.nn as nn
+    torch.manual_seed(seed)
+    return nn.Sequential(nn.Linear(i, 512), nn.ELU(), nn.Linear(512, 256), nn.ELU(), nn.Linear(256, 128), nn.ELU(), nn.Linear(128, o)).cuda()
+
+
+@pytest.mark.parametrize("obs,mb,gather", [(235, 24576, True), (169, 24576, True), (235, 1000, True), (169, 37, False)])
+def test_wide_mlp_kernels_match_autograd(obs, mb, gather):
+    """lg_mlp_wide_forward / lg_mlp_wide_backward (layer-wise f32-MFMA GEMMs, csrc/lg_gemm.h) for the [235 | 169, 512, 256, 128, 12 | 1]
+    networks of configs 3-5 (legged_robot_config.py:205-208) against torch autograd in float64 on the same modules; mb = 24 576 is
+    the mini-batch of the reference's PPO settings (98 304 transitions / 4)."""
+    import time
+    from legged_games_gym_amd.rl.mlp_kernels import WideMlpTrainer
+    actor, critic = _wide_mlp(obs, 12, 0), _wide_mlp(obs, 1, 1)
+    R = 40000
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(R, obs, device="cuda", generator=g)
+    rows = torch.randperm(R, device="cuda", generator=g)[:mb] if gather else None
+    tr = WideMlpTrainer([actor, critic], [x, x], mb)
+    assert tr.supported and not tr.has_fused_minibatch
+    mu, val = tr.forward(rows)
+    xb = (x[rows] if gather else x[:mb]).double()
+    a64, c64 = copy.deepcopy(actor).double(), copy.deepcopy(critic).double()
+    mu_ref, val_ref = a64(xb), c64(xb)
+    assert float((mu.double() - mu_ref.detach()).abs().max()) < 2e-5 and float((val.double() - val_ref.detach()).abs().max()) < 2e-5
+    d_mu = torch.randn(mb, 12, device="cuda", generator=g) / mb
+    d_val = torch.randn(mb, 1, device="cuda", generator=g) / mb
+    torch.autograd.backward([mu_ref, val_ref], [d_mu.double(), d_val.double()])
+    want = [p.grad.clone() for net in (a64, c64) for p in net.parameters()]
+    for net in (actor, critic):
+        for p in net.parameters():
+            p.grad = torch.full_like(p, float("nan"))    # the kernels overwrite every element
+    tr.refresh()
+    tr.grad_outputs[0].copy_(d_mu); tr.grad_outputs[1].copy_(d_val)
+    tr.backward(rows)
+    got = [p.grad for net in (actor, critic) for p in net.parameters()]
+    for w, h in zip(want, got):
+        scale = float(w.abs().max()) + 1e-12
+        assert float((w - h.double()).abs().max()) < 1e-4 * scale + 1e-10, (w.shape, float((w - h.double()).abs().max()), scale)
+    first = [h.clone() for h in got]                     # fixed reduction order: bit-reproducible
+    tr.forward(rows); tr.backward(rows)
+    assert all(torch.equal(a, b) for a, b in zip(first, got))
+    if mb == 24576:                                      # informative: time of one forward + backward of both nets
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(10):
+            tr.forward(rows); tr.backward(rows)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 100
+        flops = 6.0 * mb * sum(p.numel() for net in (actor, critic) for p in net.parameters() if p.dim() == 2)
+        print(f"wide MLP forward + backward, obs {obs}, mb {mb}: {ms:.3f} ms = {flops / ms / 1e9:.1f} TFLOP/s (f32 MFMA peak 157)")
