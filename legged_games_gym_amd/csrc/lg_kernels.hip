@@ -2027,7 +2027,7 @@ static void wide_layout(const lg_mlp_net &n, int mb, WideLayout &L) {
     for (int l = 1; l <= 3; l++) { L.g[l] = o; o += (size_t)mb * n.dims[l]; }
     size_t pmax = 0;
     for (int l = 0; l < 4; l++) {
-        const int tiles = ((n.dims[l + 1] + LG_GT - 1) / LG_GT) * ((n.dims[l] + 1 + LG_GT - 1) / LG_GT);
+        const int tiles = ((n.dims[l + 1] + LG_GT - 1) / LG_GT) * ((n.dims[l] + LG_GT - 1) / LG_GT);
         int sp = (384 + tiles - 1) / tiles;                                   // enough workgroups for the chip: tiles x splits >= ~1.5 x CUs
         if (sp > LG_WIDE_MAX_SPLITS) sp = LG_WIDE_MAX_SPLITS;
         int chunk = (mb + sp - 1) / sp;
@@ -2077,7 +2077,7 @@ int lg_mlp_wide_forward(const lg_mlp_net *nets, int32_t n_nets, const int64_t *r
             g.A = l == 0 ? nets[n].input : ws + L.x[l]; g.lda = d[l];
             g.B = nets[n].weights[l]; g.ldb = d[l]; g.bias = nets[n].biases[l];
             g.C = l == 3 ? nets[n].output : ws + L.x[l + 1]; g.ldc = d[l + 1];
-            g.M = mb; g.N = d[l + 1]; g.K = d[l]; g.elu = l < 3; g.splits = 1; g.k_chunk = g.K; g.ones_col = -1;
+            g.M = mb; g.N = d[l + 1]; g.K = d[l]; g.elu = l < 3; g.splits = 1; g.k_chunk = g.K;
             g.tiles_m = (g.M + LG_GT - 1) / LG_GT; g.tiles_n = (g.N + LG_GT - 1) / LG_GT;
             if (g.tiles_m > gx) gx = g.tiles_m;
             if (g.tiles_n > gy) gy = g.tiles_n;
@@ -2113,8 +2113,8 @@ int lg_mlp_wide_backward(const lg_mlp_net *nets, int32_t n_nets, const int64_t *
             g.A = l == 3 ? nets[n].grad_output : ws + L.g[l + 1]; g.lda = d[l + 1];
             g.B = l == 0 ? nets[n].input : ws + L.x[l]; g.ldb = d[l];
             g.C = ws + L.part; g.ldc = d[l] + 1;
-            g.M = d[l + 1]; g.N = d[l]; g.K = mb; g.splits = L.splits[l]; g.k_chunk = L.kchunk[l]; g.ones_col = d[l];
-            g.tiles_m = (g.M + LG_GT - 1) / LG_GT; g.tiles_n = (d[l] + 1 + LG_GT - 1) / LG_GT;
+            g.M = d[l + 1]; g.N = d[l]; g.K = mb; g.splits = L.splits[l]; g.k_chunk = L.kchunk[l];
+            g.tiles_m = (g.M + LG_GT - 1) / LG_GT; g.tiles_n = (d[l] + LG_GT - 1) / LG_GT;
             if (g.tiles_m > gx) gx = g.tiles_m;
             if (g.tiles_n * g.splits > gy) gy = g.tiles_n * g.splits;
             r.part[n] = ws + L.part; r.gw[n] = nets[n].grad_weights[l]; r.gb[n] = nets[n].grad_biases[l];
@@ -2136,7 +2136,7 @@ int lg_mlp_wide_backward(const lg_mlp_net *nets, int32_t n_nets, const int64_t *
             g.A = l == 3 ? nets[n].grad_output : ws + L.g[l + 1]; g.lda = d[l + 1];
             g.B = nets[n].weights[l]; g.ldb = d[l];
             g.C = ws + L.g[l]; g.ldc = d[l]; g.act = ws + L.x[l];
-            g.M = mb; g.N = d[l]; g.K = d[l + 1]; g.splits = 1; g.k_chunk = g.K; g.ones_col = -1;
+            g.M = mb; g.N = d[l]; g.K = d[l + 1]; g.splits = 1; g.k_chunk = g.K;
             g.tiles_m = (g.M + LG_GT - 1) / LG_GT; g.tiles_n = (g.N + LG_GT - 1) / LG_GT;
             if (g.tiles_m > gx) gx = g.tiles_m;
             if (g.tiles_n > gy) gy = g.tiles_n;
