@@ -258,6 +258,10 @@ int  lg_mlp_backward(const lg_mlp_net *nets, int32_t n_nets, const int64_t *rows
  * (csrc/lg_gemm.h).  The activations of the forward pass stay in `workspace` (lg_mlp_wide_workspace_bytes(nets, n_nets, mb)
  * bytes) for the backward pass that follows; weight gradients are summed in a fixed order (bit-reproducible). */
 size_t lg_mlp_wide_workspace_bytes(const lg_mlp_net *nets, int32_t n_nets, int32_t mb);
+/* Arithmetic of the lg_mlp_wide_* GEMMs: 0 = exact f32 MFMA (bitwise a k-ordered fmaf chain); 1 (default) = split-bf16, every f32
+ * operand as hi + lo bf16 and every product as hi*hi + hi*lo + lo*hi with f32 accumulation (relative error of a product ~2^-15, about
+ * 5 x the f32 rate).  Process-wide; returns the previous setting. */
+int  lg_mlp_wide_set_precision(int mode);
 int  lg_mlp_wide_forward(const lg_mlp_net *nets, int32_t n_nets, const int64_t *rows, int32_t mb, float *workspace, size_t workspace_bytes,
                          void *stream);
 int  lg_mlp_wide_backward(const lg_mlp_net *nets, int32_t n_nets, const int64_t *rows, int32_t mb, float *workspace, size_t workspace_bytes,

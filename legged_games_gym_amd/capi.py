@@ -259,6 +259,7 @@ def bind_prototypes(lib, prefix: str):
         lib.lg_mlp_backward.restype = C.c_int
         lib.lg_mlp_wide_workspace_bytes.argtypes = [C.POINTER(lg_mlp_net), i32, i32]
         lib.lg_mlp_wide_workspace_bytes.restype = C.c_size_t
+        lib.lg_mlp_wide_set_precision.argtypes, lib.lg_mlp_wide_set_precision.restype = [C.c_int], C.c_int
         lib.lg_mlp_wide_forward.argtypes = [C.POINTER(lg_mlp_net), i32, vp, i32, vp, C.c_size_t, vp]
         lib.lg_mlp_wide_forward.restype = C.c_int
         lib.lg_mlp_wide_backward.argtypes = [C.POINTER(lg_mlp_net), i32, vp, i32, vp, C.c_size_t, vp]
@@ -285,7 +286,7 @@ EXPORTED_SYMBOLS = ["lg_create", "lg_destroy", "lg_bind", "lg_step", "lg_reset_i
                     "lg_physics_substep", "lg_compute_observations_only", "lg_set_params", "lg_last_error",
                     "lg_abi_version", "lg_sizeof", "lg_set_obs_buffer", "lg_policy_create", "lg_policy_destroy", "lg_policy_act",
                     "lg_step_policy", "lg_gae_returns", "lg_ppo_loss", "lg_policy_load_device", "lg_mlp_forward",
-                    "lg_mlp_workspace_bytes", "lg_mlp_backward", "lg_mlp_wide_workspace_bytes", "lg_mlp_wide_forward", "lg_mlp_wide_backward", "lg_adam_step", "lg_rollout_record", "lg_mlp_trace", "lg_ppo_minibatch"]
+                    "lg_mlp_workspace_bytes", "lg_mlp_backward", "lg_mlp_wide_workspace_bytes", "lg_mlp_wide_forward", "lg_mlp_wide_backward", "lg_mlp_wide_set_precision", "lg_adam_step", "lg_rollout_record", "lg_mlp_trace", "lg_ppo_minibatch"]
 
 
 def load_library():

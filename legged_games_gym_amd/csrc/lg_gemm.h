@@ -62,6 +62,56 @@ LG_DEV float4 load4(const float *p, int nv) {
     return r;
 }
 
+// Epilogue of both builds.  C/D map of a 32 x 32 MFMA tile: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) -- one
+// column per lane, so storing straight from the accumulators is 64 dword stores per thread, and the kernels were store-ISSUE
+// bound (~1 TB/s of output whatever the K depth).  Each wave therefore turns its 64 x 64 result, 32 rows at a time, through a
+// private 8 KB LDS patch ([32][64] floats, carved from the stage buffers after the main loop) and writes it row-wise: a lane owns
+// 4 consecutive columns (16 lanes = one 256-byte row segment), 16 dwordx4 stores per thread.  Bias / stored post-activations
+// are read the same way (float4) BEFORE the stores of their batch.
+template <int MODE>
+LG_DEV void gemm_epilogue(const GemmNet &N, float *C, const f32x16g (&acc)[2][2], int m0, int n0, int wy, int wx, int lane, float *lds_scratch) {
+    const int li = lane & 31, lh = lane >> 5, wave = 2 * wy + wx;
+    float (*ep)[64] = reinterpret_cast<float (*)[64]>(lds_scratch + wave * 32 * 64);
+    const int cq = 4 * (lane & 15), col = n0 + 64 * wx + cq;              // this lane's 4 columns in the row-wise phase
+    const int nv = max(0, min(4, N.N - col));
+    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (MODE == GEMM_FWD) bias = load4(N.bias + col, nv);
+    const bool vec_ok = (N.ldc & 3) == 0;                                  // rows of C start 16-byte aligned
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int c = 0; c < 16; c++) ep[(c & 3) + 8 * (c >> 2) + 4 * lh][32 * j + li] = acc[i][j][c];
+        __builtin_amdgcn_wave_barrier();                                   // one wave, LDS in order: its own writes are visible to its reads
+        float4 v[8], xa[8];
+#pragma unroll
+        for (int p = 0; p < 8; p++) {
+            const int rr = 4 * p + (lane >> 4), row = m0 + 64 * wy + 32 * i + rr;
+            v[p] = *reinterpret_cast<const float4 *>(&ep[rr][cq]);
+            if (MODE == GEMM_DX) xa[p] = load4(N.act + (size_t)min(row, N.M - 1) * N.ldc + col, row < N.M ? nv : 0);
+        }
+#pragma unroll
+        for (int p = 0; p < 8; p++) {
+            const int rr = 4 * p + (lane >> 4), row = m0 + 64 * wy + 32 * i + rr;
+            if (row >= N.M || nv <= 0) continue;
+            float4 o = v[p];
+            if (MODE == GEMM_FWD) {
+                o.x += bias.x; o.y += bias.y; o.z += bias.z; o.w += bias.w;
+                if (N.elu) { o.x = elu1(o.x); o.y = elu1(o.y); o.z = elu1(o.z); o.w = elu1(o.w); }
+            }
+            if (MODE == GEMM_DX) {
+                o.x *= (xa[p].x > 0.f ? 1.f : xa[p].x + 1.f); o.y *= (xa[p].y > 0.f ? 1.f : xa[p].y + 1.f);
+                o.z *= (xa[p].z > 0.f ? 1.f : xa[p].z + 1.f); o.w *= (xa[p].w > 0.f ? 1.f : xa[p].w + 1.f);
+            }
+            float *dst = C + (size_t)row * N.ldc + col;
+            if (nv == 4 && vec_ok) *reinterpret_cast<float4 *>(dst) = o;
+            else { dst[0] = o.x; if (nv > 1) dst[1] = o.y; if (nv > 2) dst[2] = o.z; if (nv > 3) dst[3] = o.w; }
+        }
+    }
+}
+
 // ---- global -> register staging: 8 floats per thread and operand as two 4-vectors along the operand's memory-contiguous direction.
 // A tile element is (r, k): r = index on the output-tile side (0..127), k = reduction index inside the stage (0..15).
 //   k-contiguous operand (A of FWD / DX, B of FWD):  thread t holds k = 4 (t & 3) .. +3 of rows r = (t >> 2) + 64 e,  e = 0, 1
@@ -189,36 +239,194 @@ __global__ void __launch_bounds__(256) k_gemm_wide(const GemmArgs G) {
         if (more) store_stage(st[(s + 1) & 1]);
         __syncthreads();
     }
-    // ---- epilogue.  C/D map of the 32 x 32 tile: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
     float *C = N.C + (MODE == GEMM_DW ? (size_t)split * N.M * N.ldc : 0);
     if (MODE == GEMM_DW && tile_n == 0 && t < LG_GT && m0 + t < N.M) C[(size_t)(m0 + t) * N.ldc + N.N] = colsum;      // bias-gradient column
+    gemm_epilogue<MODE>(N, C, acc, m0, n0, wy, wx, lane, reinterpret_cast<float *>(&st));
+}
+
+// ------------------------------------------------------------------ split-bf16 ("bf16x3") build of the same three GEMMs
+// v_mfma_f32_32x32x16_bf16 runs at 16 x the f32-MFMA rate.  Every f32 operand x is split ONCE, when its tile is written to LDS, into
+// hi = bf16(x) and lo = bf16(x - hi) (16 significand bits together), and each product is formed as hi*hi + hi*lo + lo*hi with f32
+// accumulation: three MFMAs instead of one at 16 x the rate, i.e. ~5 x the f32 path; the dropped lo*lo term and the 16-bit
+// operands bound the relative error of a product by ~2^-15.  HBM traffic, tiling and epilogues are those of k_gemm_wide; the
+// LDS images become [row][k] bf16 (k-contiguous, 80-byte rows: conflict-free ds_read_b128 fragments of 8 k-values), one pair
+// (hi, lo) per operand; stage depth 32.  Selected by lg_mlp_wide_set_precision (default) -- the exact-f32 kernels stay available.
+#define LG_BK 32                       // k depth of one stage
+#define LG_BLD 40                      // bf16 per LDS image row (32 + 8 pad): 80 bytes
+typedef __bf16 bf16x8g __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4g __attribute__((ext_vector_type(4)));
+typedef float f32x4g __attribute__((ext_vector_type(4)));
+struct GemmStageB { __bf16 ahi[LG_GT][LG_BLD], alo[LG_GT][LG_BLD], bhi[LG_GT][LG_BLD], blo[LG_GT][LG_BLD]; };      // 40 KB
+
+LG_DEV void split4(float4 x, bf16x4g &hi, bf16x4g &lo) {
+    const f32x4g v = {x.x, x.y, x.z, x.w};
+    hi = __builtin_convertvector(v, bf16x4g);
+    lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4g), bf16x4g);
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256) k_gemm_wide_bf16x3(const GemmArgs G) {
+    const GemmNet &N = G.net[blockIdx.z];
+    const int tile_m = blockIdx.x, tile_n = blockIdx.y % N.tiles_n, split = MODE == GEMM_DW ? blockIdx.y / N.tiles_n : 0;
+    if (tile_m >= N.tiles_m || blockIdx.y >= N.tiles_n * (MODE == GEMM_DW ? N.splits : 1)) return;
+    __shared__ GemmStageB st;
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, wy = wave >> 1, wx = wave & 1;
+    const int m0 = tile_m * LG_GT, n0 = tile_n * LG_GT;
+    const int k_begin = MODE == GEMM_DW ? split * N.k_chunk : 0;
+    const int k_end = MODE == GEMM_DW ? min(N.K, k_begin + N.k_chunk) : N.K;
+    constexpr bool A_KC = MODE != GEMM_DW, B_KC = MODE == GEMM_FWD;
+    // thread -> tile elements.  k-contiguous operand: row r = t >> 1, 16 consecutive k from 16 (t & 1).
+    //                           r-contiguous operand: the 4 x 4 block rows r = 4 (t & 31) .. +3, k = 4 (t >> 5) .. +3.
+    const float *pa; int na;
+    if (A_KC) {
+        const int m = m0 + (t >> 1);
+        na = m < N.M;
+        const size_t row = (MODE == GEMM_FWD && G.gather_a_rows && na) ? (size_t)G.rows[m] : (size_t)(na ? m : 0);
+        pa = N.A + row * N.lda;
+    } else {
+        const int m = m0 + 4 * (t & 31);
+        na = max(0, min(4, N.M - m));
+        pa = N.A + m;
+    }
+    const float *pb; int nb;
+    if (B_KC) {
+        const int n = n0 + (t >> 1);
+        nb = n < N.N;
+        pb = N.B + (size_t)(nb ? n : 0) * N.ldb;
+    } else {
+        const int n = n0 + 4 * (t & 31);
+        nb = max(0, min(4, N.N - n));
+        pb = N.B + n;
+    }
+    int64_t brow_next[4] = {0, 0, 0, 0};
+    if (MODE == GEMM_DW && G.gather_b_k) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) brow_next[c] = G.rows[min(k_begin + 4 * (t >> 5) + c, max(k_end - 1, 0))];
+    }
+    float4 ra[4], rb[4];
+    auto load_stage = [&](int kb) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            if (A_KC) { const int k = kb + 16 * (t & 1) + 4 * c; ra[c] = load4(pa + k, na ? k_end - k : 0); }
+            else { const int k = kb + 4 * (t >> 5) + c; ra[c] = load4(pa + (size_t)min(k, k_end - 1) * N.lda, k < k_end ? na : 0); }
+            if (B_KC) { const int k = kb + 16 * (t & 1) + 4 * c; rb[c] = load4(pb + k, nb ? k_end - k : 0); }
+            else {
+                const int k = kb + 4 * (t >> 5) + c;
+                size_t row = (size_t)min(k, k_end - 1);
+                if (MODE == GEMM_DW && G.gather_b_k) { row = (size_t)brow_next[c]; brow_next[c] = G.rows[min(k + LG_BK, k_end - 1)]; }
+                rb[c] = load4(pb + row * N.ldb, k < k_end ? nb : 0);
+            }
+        }
+    };
+    float colsum = 0.0f;                                  // DW, first tile column: this thread's share of db (its 4 features x 4 rows per stage)
+    float cs4[4] = {0.f, 0.f, 0.f, 0.f};
+    auto store_stage = [&]() {
+        auto put_kc = [&](__bf16 (*hi)[LG_BLD], __bf16 (*lo)[LG_BLD], const float4 (&v)[4]) {
+            const int r = t >> 1, k = 16 * (t & 1);
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                bf16x4g h0, l0, h1, l1;
+                split4(v[2 * h], h0, l0); split4(v[2 * h + 1], h1, l1);
+                *reinterpret_cast<bf16x8g *>(&hi[r][k + 8 * h]) = bf16x8g{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+                *reinterpret_cast<bf16x8g *>(&lo[r][k + 8 * h]) = bf16x8g{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+            }
+        };
+        auto put_rc = [&](__bf16 (*hi)[LG_BLD], __bf16 (*lo)[LG_BLD], const float4 (&v)[4]) {
+            const int r = 4 * (t & 31), k = 4 * (t >> 5);
+            bf16x4g h[4], l[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) split4(v[c], h[c], l[c]);            // h[c][i]: k + c, row r + i
+#pragma unroll
+            for (int i = 0; i < 4; i++) {                                     // register transpose: 4 consecutive k of row r + i
+                *reinterpret_cast<bf16x4g *>(&hi[r + i][k]) = bf16x4g{h[0][i], h[1][i], h[2][i], h[3][i]};
+                *reinterpret_cast<bf16x4g *>(&lo[r + i][k]) = bf16x4g{l[0][i], l[1][i], l[2][i], l[3][i]};
+            }
+        };
+        if (A_KC) put_kc(st.ahi, st.alo, ra); else put_rc(st.ahi, st.alo, ra);
+        if (B_KC) put_kc(st.bhi, st.blo, rb); else put_rc(st.bhi, st.blo, rb);
+        if (MODE == GEMM_DW && tile_n == 0) {             // bias gradient: exact f32 column sums of the G tile this thread just staged
+#pragma unroll
+            for (int c = 0; c < 4; c++) { cs4[0] += ra[c].x; cs4[1] += ra[c].y; cs4[2] += ra[c].z; cs4[3] += ra[c].w; }
+        }
+    };
+    f32x16g acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int col = n0 + 64 * wx + 32 * j + li;
+        for (int j = 0; j < 2; j++)
 #pragma unroll
-            for (int c = 0; c < 16; c++) {
-                const int row = m0 + 64 * wy + 32 * i + (c & 3) + 8 * (c >> 2) + 4 * lh;
-                if (row < N.M && col < N.N) {
-                    float v = acc[i][j][c];
-                    if (MODE == GEMM_FWD) { v += N.bias[col]; if (N.elu) v = elu1(v); }
-                    if (MODE == GEMM_DX) { const float x = N.act[(size_t)row * N.ldc + col]; v *= (x > 0.0f ? 1.0f : x + 1.0f); }
-                    C[(size_t)row * N.ldc + col] = v;
-                }
+            for (int c = 0; c < 16; c++) acc[i][j][c] = 0.0f;
+    const int n_stage = (k_end - k_begin + LG_BK - 1) / LG_BK;
+    const int li = lane & 31, lh = lane >> 5;
+    if (n_stage > 0) load_stage(k_begin);
+    for (int s = 0; s < n_stage; s++) {
+        store_stage();                                            // registers of stage s -> LDS (the previous stage's readers passed the barrier below)
+        __syncthreads();
+        if (s + 1 < n_stage) load_stage(k_begin + (s + 1) * LG_BK);      // in flight during this stage's MFMAs
+#pragma unroll
+        for (int ks = 0; ks < LG_BK; ks += 16) {
+            bf16x8g ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                ah[i] = *reinterpret_cast<const bf16x8g *>(&st.ahi[64 * wy + 32 * i + li][ks + 8 * lh]);
+                al[i] = *reinterpret_cast<const bf16x8g *>(&st.alo[64 * wy + 32 * i + li][ks + 8 * lh]);
+                bh[i] = *reinterpret_cast<const bf16x8g *>(&st.bhi[64 * wx + 32 * i + li][ks + 8 * lh]);
+                bl[i] = *reinterpret_cast<const bf16x8g *>(&st.blo[64 * wx + 32 * i + li][ks + 8 * lh]);
             }
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);     // small terms first
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
         }
+        __syncthreads();                                          // all fragment reads of this stage done before the next store
+    }
+    float *C = N.C + (MODE == GEMM_DW ? (size_t)split * N.M * N.ldc : 0);
+    if (MODE == GEMM_DW && tile_n == 0) {                         // fold the 8 k-groups (t >> 5) of each feature through LDS, fixed order
+        float *red = reinterpret_cast<float *>(&st) + 8192;       // beyond the 32 KB the epilogue's LDS patches use
+#pragma unroll
+        for (int i = 0; i < 4; i++) red[(t >> 5) * LG_GT + 4 * (t & 31) + i] = cs4[i];
+        __syncthreads();
+        if (t < LG_GT) {
+#pragma unroll
+            for (int g = 0; g < 8; g++) colsum += red[g * LG_GT + t];
+            if (m0 + t < N.M) C[(size_t)(m0 + t) * N.ldc + N.N] = colsum;
+        }
+    }
+    gemm_epilogue<MODE>(N, C, acc, m0, n0, wy, wx, lane, reinterpret_cast<float *>(&st));
+}
+
+// Layer-0 operands in aligned, gather-free form: x0p[m][0 .. K0p) = x[rows[m]][0 .. d0) (zero padded to K0p = round-up of d0 to 4
+// floats) and w0p[n][0 .. K0p) likewise.  The input rows of the rough tasks are 235 / 169 floats: 940-byte strides leave every
+// 16-byte load of the GEMMs unaligned, and the row gather adds a dependent load; one copy pass per mini-batch removes both from
+// the two GEMMs that read the inputs (forward layer 0, dW of layer 0).
+struct WidePrepArgs { const float *x[2], *w[2]; float *xp[2], *wp[2]; const int64_t *rows; int d0[2], d1[2], k0p[2], mb; };
+__global__ void __launch_bounds__(256) k_wide_prep(const WidePrepArgs P) {
+    const int z = blockIdx.y, kp = P.k0p[z], d0 = P.d0[z], q = kp / 4;
+    const size_t nx = (size_t)P.mb * q, nw = (size_t)P.d1[z] * q;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < nx + nw; i += (size_t)gridDim.x * 256) {
+        const bool isx = i < nx;
+        const size_t j = isx ? i : i - nx;
+        const int r = (int)(j / q), c = 4 * (int)(j % q);
+        const float *src = isx ? P.x[z] + (size_t)(P.rows ? P.rows[r] : r) * d0 : P.w[z] + (size_t)r * d0;
+        float4 v = load4(src + c, d0 - c);
+        *reinterpret_cast<float4 *>((isx ? P.xp[z] : P.wp[z]) + (size_t)r * kp + c) = v;
+    }
 }
 
 // dW / db from the per-split partials [splits][N][K + 1] in a fixed order: gw[n][k] (torch layout), gb[n]
-struct WideReduceArgs { const float *part[2]; float *gw[2], *gb[2]; int N[2], K[2], splits[2]; };
+struct WideReduceArgs { const float *part[2]; float *gw[2], *gb[2]; int N[2], K[2], ld[2], splits[2]; };     // ld: row stride of a partial (K + 1 rounded up to 4)
 __global__ void __launch_bounds__(256) k_wide_reduce(const WideReduceArgs R) {
-    const int z = blockIdx.y, N = R.N[z], K = R.K[z], ld = K + 1;
+    const int z = blockIdx.y, N = R.N[z], K = R.K[z], ld = R.ld[z];
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N * ld) return;
+    const int n = i / ld, k = i % ld;
+    if (k > K) return;
     float s = 0.0f;
     for (int p = 0; p < R.splits[z]; p++) s += R.part[z][(size_t)p * N * ld + i];
-    const int n = i / ld, k = i % ld;
     if (k < K) R.gw[z][(size_t)n * K + k] = s;
     else R.gb[z][n] = s;
 }

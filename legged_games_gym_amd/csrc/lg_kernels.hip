@@ -2020,7 +2020,7 @@ int lg_ppo_minibatch(const lg_mlp_net *nets, const int64_t *rows, int32_t mb, co
 }
 
 // ---- learner kernels for the wide MLPs (lg_gemm.h): per layer a tiled f32-MFMA GEMM with the element-wise work in its epilogue
-struct WideLayout { size_t x[4], g[4], part, total; int splits[4]; int kchunk[4]; };      // float offsets into one net's workspace slice
+struct WideLayout { size_t x[4], g[4], part, x0p, w0p, total; int splits[4]; int kchunk[4]; int k0p; };      // float offsets into one net's workspace slice
 static void wide_layout(const lg_mlp_net &n, int mb, WideLayout &L) {
     size_t o = 0;
     for (int l = 1; l <= 3; l++) { L.x[l] = o; o += (size_t)mb * n.dims[l]; }
@@ -2031,14 +2031,18 @@ static void wide_layout(const lg_mlp_net &n, int mb, WideLayout &L) {
         int sp = (384 + tiles - 1) / tiles;                                   // enough workgroups for the chip: tiles x splits >= ~1.5 x CUs
         if (sp > LG_WIDE_MAX_SPLITS) sp = LG_WIDE_MAX_SPLITS;
         int chunk = (mb + sp - 1) / sp;
-        chunk = ((chunk + LG_GK - 1) / LG_GK) * LG_GK;
-        if (chunk < LG_GK) chunk = LG_GK;
+        chunk = ((chunk + LG_BK - 1) / LG_BK) * LG_BK;       /* multiple of both kernels' stage depths */
+        if (chunk < LG_BK) chunk = LG_BK;
         sp = (mb + chunk - 1) / chunk;
         L.splits[l] = sp; L.kchunk[l] = chunk;
-        const size_t p = (size_t)sp * n.dims[l + 1] * (n.dims[l] + 1);
+        const size_t p = (size_t)sp * n.dims[l + 1] * ((n.dims[l] + 1 + 3) & ~3);
         if (p > pmax) pmax = p;
     }
     L.part = o; o += pmax;
+    o = (o + 3) & ~(size_t)3;
+    L.k0p = (n.dims[0] + 3) & ~3;                     // aligned, gather-free copies of the layer-0 operands (k_wide_prep)
+    L.x0p = o; o += (size_t)mb * L.k0p;
+    L.w0p = o; o += (size_t)n.dims[1] * L.k0p;
     L.total = (o + 3) & ~(size_t)3;
 }
 static int wide_check(const lg_mlp_net *nets, int32_t n_nets, int32_t mb) {
@@ -2051,7 +2055,15 @@ static int wide_check(const lg_mlp_net *nets, int32_t n_nets, int32_t mb) {
     return 0;
 }
 
+static int g_wide_precision = 1;       /* 0: exact f32 MFMA (k_gemm_wide), 1: split-bf16 (k_gemm_wide_bf16x3) */
+#define LAUNCH_WIDE(MODE, GRID, ARGS)                                                                              \
+    { if (g_wide_precision == 0) hipLaunchKernelGGL((lg::k_gemm_wide<MODE>), GRID, dim3(256), 0, st, ARGS);       \
+      else hipLaunchKernelGGL((lg::k_gemm_wide_bf16x3<MODE>), GRID, dim3(256), 0, st, ARGS); }
+
 extern "C" {
+
+/* 0: exact f32 MFMA; 1 (default): split-bf16 products hi*hi + hi*lo + lo*hi with f32 accumulation (~2^-15 relative, ~5 x faster).  Returns the previous setting. */
+int lg_mlp_wide_set_precision(int mode) { const int old = g_wide_precision; if (mode == 0 || mode == 1) g_wide_precision = mode; return old; }
 
 size_t lg_mlp_wide_workspace_bytes(const lg_mlp_net *nets, int32_t n_nets, int32_t mb) {
     if (!nets || mb <= 0) return 0;
@@ -2065,17 +2077,33 @@ int lg_mlp_wide_forward(const lg_mlp_net *nets, int32_t n_nets, const int64_t *r
     if (!workspace || workspace_bytes < lg_mlp_wide_workspace_bytes(nets, n_nets, mb)) return fail(-1, "workspace too small (lg_mlp_wide_workspace_bytes)");
     for (int n = 0; n < n_nets; n++) if (!nets[n].output) return fail(-1, "null output");
     hipStream_t st = (hipStream_t)stream;
+    {   // layer-0 operands: gathered, padded, aligned
+        lg::WidePrepArgs pr; memset(&pr, 0, sizeof pr);
+        float *ws = workspace;
+        size_t work = 0;
+        for (int n = 0; n < n_nets; n++) {
+            WideLayout L; wide_layout(nets[n], mb, L);
+            pr.x[n] = nets[n].input; pr.w[n] = nets[n].weights[0]; pr.xp[n] = ws + L.x0p; pr.wp[n] = ws + L.w0p;
+            pr.d0[n] = nets[n].dims[0]; pr.d1[n] = nets[n].dims[1]; pr.k0p[n] = L.k0p;
+            const size_t w_ = ((size_t)mb + nets[n].dims[1]) * (L.k0p / 4);
+            if (w_ > work) work = w_;
+            ws += L.total;
+        }
+        pr.rows = rows; pr.mb = mb;
+        int blocks = (int)((work + 255) / 256); if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(lg::k_wide_prep, dim3(blocks, n_nets), dim3(256), 0, st, pr);
+    }
     for (int l = 0; l < 4; l++) {
         lg::GemmArgs a; memset(&a, 0, sizeof a);
-        a.rows = rows; a.gather_a_rows = (l == 0 && rows) ? 1 : 0; a.mb = mb;
+        a.rows = nullptr; a.gather_a_rows = 0; a.mb = mb;
         int gx = 0, gy = 0;
         float *ws = workspace;
         for (int n = 0; n < n_nets; n++) {
             WideLayout L; wide_layout(nets[n], mb, L);
             lg::GemmNet &g = a.net[n];
             const int32_t *d = nets[n].dims;
-            g.A = l == 0 ? nets[n].input : ws + L.x[l]; g.lda = d[l];
-            g.B = nets[n].weights[l]; g.ldb = d[l]; g.bias = nets[n].biases[l];
+            g.A = l == 0 ? ws + L.x0p : ws + L.x[l]; g.lda = l == 0 ? L.k0p : d[l];
+            g.B = l == 0 ? ws + L.w0p : nets[n].weights[l]; g.ldb = l == 0 ? L.k0p : d[l]; g.bias = nets[n].biases[l];
             g.C = l == 3 ? nets[n].output : ws + L.x[l + 1]; g.ldc = d[l + 1];
             g.M = mb; g.N = d[l + 1]; g.K = d[l]; g.elu = l < 3; g.splits = 1; g.k_chunk = g.K;
             g.tiles_m = (g.M + LG_GT - 1) / LG_GT; g.tiles_n = (g.N + LG_GT - 1) / LG_GT;
@@ -2083,7 +2111,7 @@ int lg_mlp_wide_forward(const lg_mlp_net *nets, int32_t n_nets, const int64_t *r
             if (g.tiles_n > gy) gy = g.tiles_n;
             ws += L.total;
         }
-        hipLaunchKernelGGL((lg::k_gemm_wide<lg::GEMM_FWD>), dim3(gx, gy, n_nets), dim3(256), 0, st, a);
+        LAUNCH_WIDE(lg::GEMM_FWD, dim3(gx, gy, n_nets), a)
     }
     HIP_TRY(hipGetLastError());
     return 0;
@@ -2103,7 +2131,7 @@ int lg_mlp_wide_backward(const lg_mlp_net *nets, int32_t n_nets, const int64_t *
         // dW_l, db_l (split over the mini-batch rows) ...
         lg::GemmArgs a; memset(&a, 0, sizeof a);
         lg::WideReduceArgs r; memset(&r, 0, sizeof r);
-        a.rows = rows; a.gather_b_k = (l == 0 && rows) ? 1 : 0; a.mb = mb;
+        a.rows = nullptr; a.gather_b_k = 0; a.mb = mb;          // layer 0 reads the gathered copy the forward pass left in the workspace
         int gx = 0, gy = 0, rmax = 0;
         float *ws = workspace;
         for (int n = 0; n < n_nets; n++) {
@@ -2111,18 +2139,18 @@ int lg_mlp_wide_backward(const lg_mlp_net *nets, int32_t n_nets, const int64_t *
             lg::GemmNet &g = a.net[n];
             const int32_t *d = nets[n].dims;
             g.A = l == 3 ? nets[n].grad_output : ws + L.g[l + 1]; g.lda = d[l + 1];
-            g.B = l == 0 ? nets[n].input : ws + L.x[l]; g.ldb = d[l];
-            g.C = ws + L.part; g.ldc = d[l] + 1;
+            g.B = l == 0 ? ws + L.x0p : ws + L.x[l]; g.ldb = l == 0 ? L.k0p : d[l];
+            g.C = ws + L.part; g.ldc = (d[l] + 1 + 3) & ~3;
             g.M = d[l + 1]; g.N = d[l]; g.K = mb; g.splits = L.splits[l]; g.k_chunk = L.kchunk[l];
             g.tiles_m = (g.M + LG_GT - 1) / LG_GT; g.tiles_n = (d[l] + LG_GT - 1) / LG_GT;
             if (g.tiles_m > gx) gx = g.tiles_m;
             if (g.tiles_n * g.splits > gy) gy = g.tiles_n * g.splits;
             r.part[n] = ws + L.part; r.gw[n] = nets[n].grad_weights[l]; r.gb[n] = nets[n].grad_biases[l];
-            r.N[n] = d[l + 1]; r.K[n] = d[l]; r.splits[n] = L.splits[l];
-            if (d[l + 1] * (d[l] + 1) > rmax) rmax = d[l + 1] * (d[l] + 1);
+            r.N[n] = d[l + 1]; r.K[n] = d[l]; r.ld[n] = (d[l] + 1 + 3) & ~3; r.splits[n] = L.splits[l];
+            if (d[l + 1] * r.ld[n] > rmax) rmax = d[l + 1] * r.ld[n];
             ws += L.total;
         }
-        hipLaunchKernelGGL((lg::k_gemm_wide<lg::GEMM_DW>), dim3(gx, gy, n_nets), dim3(256), 0, st, a);
+        LAUNCH_WIDE(lg::GEMM_DW, dim3(gx, gy, n_nets), a)
         hipLaunchKernelGGL(lg::k_wide_reduce, dim3((rmax + 255) / 256, n_nets), dim3(256), 0, st, r);
         if (l == 0) break;
         // ... and G_l = (G_{l+1} W_l) * elu'(X_l)
@@ -2142,7 +2170,7 @@ int lg_mlp_wide_backward(const lg_mlp_net *nets, int32_t n_nets, const int64_t *
             if (g.tiles_n > gy) gy = g.tiles_n;
             ws += L.total;
         }
-        hipLaunchKernelGGL((lg::k_gemm_wide<lg::GEMM_DX>), dim3(gx, gy, n_nets), dim3(256), 0, st, b);
+        LAUNCH_WIDE(lg::GEMM_DX, dim3(gx, gy, n_nets), b)
     }
     HIP_TRY(hipGetLastError());
     return 0;

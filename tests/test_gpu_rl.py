@@ -386,13 +386,26 @@ def _wide_mlp(i, o, seed):
     return nn.Sequential(nn.Linear(i, 512), nn.ELU(), nn.Linear(512, 256), nn.ELU(), nn.Linear(256, 128), nn.ELU(), nn.Linear(128, o)).cuda()
 
 
+@pytest.mark.parametrize("precision", [1, 0])
 @pytest.mark.parametrize("obs,mb,gather", [(235, 24576, True), (169, 24576, True), (235, 1000, True), (169, 37, False)])
-def test_wide_mlp_kernels_match_autograd(obs, mb, gather):
+def test_wide_mlp_kernels_match_autograd(obs, mb, gather, precision):
     """lg_mlp_wide_forward / lg_mlp_wide_backward (layer-wise f32-MFMA GEMMs, csrc/lg_gemm.h) for the [235 | 169, 512, 256, 128, 12 | 1]
     networks of configs 3-5 (legged_robot_config.py:205-208) against torch autograd in float64 on the same modules; mb = 24 576 is
-    the mini-batch of the reference's PPO settings (98 304 transitions / 4)."""
+    the mini-batch of the reference's PPO settings (98 304 transitions / 4).  precision 0: exact f32 MFMA; 1 (default): split-bf16
+    products (hi*hi + hi*lo + lo*hi, f32 accumulation; ~2^-15 per product) -- tolerances stated per precision."""
     import time
+    from legged_games_gym_amd import capi
     from legged_games_gym_amd.rl.mlp_kernels import WideMlpTrainer
+    lib = capi.load_library()
+    old = lib.lg_mlp_wide_set_precision(precision)
+    try:
+        _wide_mlp_check(obs, mb, gather, precision, time, WideMlpTrainer)
+    finally:
+        lib.lg_mlp_wide_set_precision(old)
+
+
+def _wide_mlp_check(obs, mb, gather, precision, time, WideMlpTrainer):
+    out_tol, grad_tol = (2e-5, 1e-4) if precision == 0 else (1e-4, 3e-4)
     actor, critic = _wide_mlp(obs, 12, 0), _wide_mlp(obs, 1, 1)
     R = 40000
     g = torch.Generator(device="cuda").manual_seed(5)
@@ -404,7 +417,7 @@ def test_wide_mlp_kernels_match_autograd(obs, mb, gather):
     xb = (x[rows] if gather else x[:mb]).double()
     a64, c64 = copy.deepcopy(actor).double(), copy.deepcopy(critic).double()
     mu_ref, val_ref = a64(xb), c64(xb)
-    assert float((mu.double() - mu_ref.detach()).abs().max()) < 2e-5 and float((val.double() - val_ref.detach()).abs().max()) < 2e-5
+    assert float((mu.double() - mu_ref.detach()).abs().max()) < out_tol and float((val.double() - val_ref.detach()).abs().max()) < out_tol
     d_mu = torch.randn(mb, 12, device="cuda", generator=g) / mb
     d_val = torch.randn(mb, 1, device="cuda", generator=g) / mb
     torch.autograd.backward([mu_ref, val_ref], [d_mu.double(), d_val.double()])
@@ -418,7 +431,7 @@ def test_wide_mlp_kernels_match_autograd(obs, mb, gather):
     got = [p.grad for net in (actor, critic) for p in net.parameters()]
     for w, h in zip(want, got):
         scale = float(w.abs().max()) + 1e-12
-        assert float((w - h.double()).abs().max()) < 1e-4 * scale + 1e-10, (w.shape, float((w - h.double()).abs().max()), scale)
+        assert float((w - h.double()).abs().max()) < grad_tol * scale + 1e-10, (w.shape, float((w - h.double()).abs().max()), scale)
     first = [h.clone() for h in got]                     # fixed reduction order: bit-reproducible
     tr.forward(rows); tr.backward(rows)
     assert all(torch.equal(a, b) for a, b in zip(first, got))
@@ -429,4 +442,4 @@ def test_wide_mlp_kernels_match_autograd(obs, mb, gather):
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) * 100
         flops = 6.0 * mb * sum(p.numel() for net in (actor, critic) for p in net.parameters() if p.dim() == 2)
-        print(f"wide MLP forward + backward, obs {obs}, mb {mb}: {ms:.3f} ms = {flops / ms / 1e9:.1f} TFLOP/s (f32 MFMA peak 157)")
+        print(f"wide MLP forward + backward, obs {obs}, mb {mb}, {'split-bf16' if precision else 'exact f32'}: {ms:.3f} ms = {flops / ms / 1e9:.1f} TFLOP/s (f32 MFMA peak 157)")
