@@ -34,7 +34,7 @@ for d in sorted(glob.glob(os.path.join(SRC, "pmc_*"))):
                 continue
             per.setdefault(k, {}).setdefault(r["Counter_Name"], {}).setdefault(r["Dispatch_Id"], 0.0)
             per[k][r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
-summary = {"round": 1, "workload": "anymal_c_flat, 4096 envs, 1 x MI355X, eager launches (bench.py --no-graph) so each dispatch has its own counter row",
+summary = {"round": int(tag[1:]) if tag[1:].isdigit() else tag, "workload": "anymal_c_flat (self-collision on), 4096 envs, 1 x MI355X, eager launches (bench.py --no-graph) so each dispatch has its own counter row",
            "command": "tools/collect_profiles.sh (rocprofv3 --pmc <group> --kernel-trace, one group per pass: FETCH_SIZE | WRITE_SIZE | SQ_*)",
            "per_launch": {}}
 with open(os.path.join(DST, f"{tag}_pmc_counters.csv"), "w", newline="") as fh:
@@ -55,6 +55,10 @@ sq = summary["per_launch"][main]
 if "SQ_INSTS_VALU" in sq:
     summary["k_step_issue"] = {"valu_per_wave": sq["SQ_INSTS_VALU"]["mean"] / 1024.0, "note": "1024 waves per launch (256 workgroups x 4 waves)",
                                "wait_any_frac_of_wave_cycles": sq["SQ_WAIT_ANY"]["mean"] / sq["SQ_WAVE_CYCLES"]["mean"],
-                               "mfma_busy_frac_of_busy_cycles": sq["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / sq["SQ_BUSY_CYCLES"]["mean"]}
+                               # SQ_BUSY_CYCLES is counted per shader engine (32 on MI355X): / 32 = the kernel's duration in cycles;
+                               # SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs
+                               "kernel_cycles": sq["SQ_BUSY_CYCLES"]["mean"] / 32.0,
+                               "mfma_busy_frac_of_busy_cycles": sq["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / (1024.0 * sq["SQ_BUSY_CYCLES"]["mean"] / 32.0),
+                               "valu_issue_frac": 4.0 * sq["SQ_INSTS_VALU"]["mean"] / (1024.0 * sq["SQ_BUSY_CYCLES"]["mean"] / 32.0)}
 json.dump(summary, open(os.path.join(DST, f"{tag}_pmc_summary.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in summary.items() if k != "per_launch"}, indent=1))
