@@ -45,7 +45,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--task", type=str, default="anymal_c_flat")
-    ap.add_argument("--num-envs", type=int, default=4096, help="envs per GPU")
+    ap.add_argument("--num-envs", type=int, default=0, help="envs per GPU (default: BASELINE.json's size for the task: 8192 for cassie, 4096 otherwise)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--policy", choices=["auto", "fused", "torch"], default="auto",
@@ -58,7 +58,10 @@ def parse_args():
     ap.add_argument("--trimesh", action="store_true", help="keep the registered mesh_type 'trimesh' (vertical faces beyond slope_treshold) instead of BASELINE.json's height-field contact")
     ap.add_argument("--min-timed-ms", type=float, default=50.0, help="a timed region shorter than this is repeated and the median reported")
     ap.add_argument("--event-steps", type=int, default=200, help="steps timed with HIP events for the step-kernel-only graph (tasks whose timed graph also holds the actor kernel)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.num_envs <= 0:
+        a.num_envs = 8192 if a.task == "cassie" else 4096           # BASELINE.json configs 2/3 (4096) and 5 (8192)
+    return a
 
 
 def spawn_workers(a):
@@ -322,7 +325,7 @@ def worker(a):
                        "envs_per_gpu": a.num_envs, "decimation": int(env.cfg.control.decimation), "sim_dt": float(env.sim_params.dt),
                        "parallelism": f"env-sharded x{world}", "state_finite": finite,
                        "launch": ("eager" if a.no_graph else f"HIP graph of {G} policy steps per replay") + (": ONE kernel, actor fused into the step (lg_step_policy)" if fused_step else " (policy + lg_step)"),
-                       "policy": "torch ops (hipBLASLt)" if use_torch else ("MFMA actor inside k_step (v_mfma_f32_16x16x4_f32, 4 waves)" if fused_step else "fused MFMA actor kernel (lg_policy_act, v_mfma_f32_16x16x4_f32)")},
+                       "policy": "torch ops (hipBLASLt)" if use_torch else ("MFMA actor inside k_step (v_mfma_f32_16x16x4_f32, 4 waves)" if fused_step else "actor kernel lg_policy_act: k_policy_act_wide, 32 envs per workgroup, split-bf16 products (hi*hi + hi*lo + lo*hi, f32 accumulate) on v_mfma_f32_32x32x16_bf16")},
             "repeats": repeats,
             "timing": f"median of {repeats} timed regions of exactly {a.steps} steps each (a region shorter than {a.min_timed_ms:g} ms is repeated)" if repeats > 1 else f"one timed region of {a.steps} steps",
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

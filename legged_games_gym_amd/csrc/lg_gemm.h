@@ -253,7 +253,6 @@ __global__ void __launch_bounds__(256) k_gemm_wide(const GemmArgs G) {
 // (hi, lo) per operand; stage depth 32.  Selected by lg_mlp_wide_set_precision (default) -- the exact-f32 kernels stay available.
 #define LG_BK 32                       // k depth of one stage
 #define LG_BLD 40                      // bf16 per LDS image row (32 + 8 pad): 80 bytes
-typedef __bf16 bf16x8g __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4g __attribute__((ext_vector_type(4)));
 typedef float f32x4g __attribute__((ext_vector_type(4)));
 struct GemmStageB { __bf16 ahi[LG_GT][LG_BLD], alo[LG_GT][LG_BLD], bhi[LG_GT][LG_BLD], blo[LG_GT][LG_BLD]; };      // 40 KB

@@ -1852,11 +1852,17 @@ static void fill_args(const lg_sim *s, KArgs &a, int64_t step) {
 template <class T> static int grid_for(int n_env_like) { return (n_env_like * T::K + LG_BLOCK - 1) / LG_BLOCK; }
 
 // ------------------------------------------------------------------ fused actor (lg_policy.h): host side
+static int g_wide_precision = 1;       /* lg_mlp_wide_set_precision: 0 = f32 MFMA kernels, 1 = split-bf16 (bf16x3) kernels, learner GEMMs and wide actor alike */
 struct lg_policy {
     int32_t dims[5];
     int     tiles[4];          // input tiles of layer 0, then hidden widths / 16
     float  *d_w[4], *d_b[4], *d_std;
     int     device;
+    // wide actors (hidden 512-256-128): split-bf16 operand stream of k_policy_act_wide next to the f32 one
+    bool    wide;
+    int     wide_ks[4], wide_ot[4];     // k-steps of 16 / output tiles of 32 per layer
+    __bf16 *d_wb[4];
+    float  *d_bb[4];
 };
 // torch Linear [out,in] -> MFMA A-operand stream [out_tile][k_step = (t,r)][lane]: W[16o + (l&15)][16t + 4(l>>4) + r]
 static void policy_pack_layer(const float *W, const float *bias, int in_dim, int out_dim, int in_tiles, int out_tiles,
@@ -2055,7 +2061,7 @@ static int wide_check(const lg_mlp_net *nets, int32_t n_nets, int32_t mb) {
     return 0;
 }
 
-static int g_wide_precision = 1;       /* 0: exact f32 MFMA (k_gemm_wide), 1: split-bf16 (k_gemm_wide_bf16x3) */
+/* g_wide_precision (defined with the fused-actor host code): 0: exact f32 MFMA (k_gemm_wide), 1: split-bf16 (k_gemm_wide_bf16x3) */
 #define LAUNCH_WIDE(MODE, GRID, ARGS)                                                                              \
     { if (g_wide_precision == 0) hipLaunchKernelGGL((lg::k_gemm_wide<MODE>), GRID, dim3(256), 0, st, ARGS);       \
       else hipLaunchKernelGGL((lg::k_gemm_wide_bf16x3<MODE>), GRID, dim3(256), 0, st, ARGS); }
@@ -2220,6 +2226,16 @@ int lg_adam_step(const lg_adam_tensor *tensors, int32_t n_tensors, float *lr, fl
 
 extern "C" {
 
+static int policy_pack_wide(lg_policy *p, const float *const weights[4], const float *const biases[4], hipStream_t st) {
+    for (int i = 0; i < 4; i++) {
+        const size_t n = (size_t)p->wide_ot[i] * p->wide_ks[i] * 512 + (size_t)p->wide_ot[i] * 32;
+        hipLaunchKernelGGL(lg::k_policy_pack_wide, dim3((unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256)), dim3(256), 0, st, weights[i], biases[i],
+                           p->dims[i], p->dims[i + 1], p->wide_ks[i], p->wide_ot[i], i == 0 ? 1 : 0, p->d_wb[i], p->d_bb[i]);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int lg_policy_load_device(lg_policy *p, const float *const weights[4], const float *const biases[4], const float *std, void *stream) {
     if (!p || !weights || !biases || !std) return fail(-1, "null argument");
     hipStream_t st = (hipStream_t)stream;
@@ -2230,6 +2246,7 @@ int lg_policy_load_device(lg_policy *p, const float *const weights[4], const flo
         hipLaunchKernelGGL(k_policy_pack, dim3((unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256)), dim3(256), 0, st, weights[i], biases[i],
                            p->dims[i], p->dims[i + 1], in_t, out_t, p->d_w[i], p->d_b[i]);
     }
+    if (p->wide) { int rc = policy_pack_wide(p, weights, biases, st); if (rc) return rc; }
     HIP_TRY(hipMemcpyAsync(p->d_std, std, p->dims[4] * sizeof(float), hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipGetLastError());
     return 0;
@@ -2244,9 +2261,10 @@ int lg_policy_create(const int32_t dims[5], const float *const weights[4], const
     lg_policy *p = new (std::nothrow) lg_policy();
     if (!p) return fail(-5, "out of host memory");
     memcpy(p->dims, dims, sizeof p->dims); p->device = device_id;
-    for (int i = 0; i < 4; i++) { p->d_w[i] = nullptr; p->d_b[i] = nullptr; }
+    for (int i = 0; i < 4; i++) { p->d_w[i] = nullptr; p->d_b[i] = nullptr; p->d_wb[i] = nullptr; p->d_bb[i] = nullptr; }
     p->d_std = nullptr;
     p->tiles[0] = (dims[0] + 15) / 16; p->tiles[1] = dims[1] / 16; p->tiles[2] = dims[2] / 16; p->tiles[3] = dims[3] / 16;
+    p->wide = dims[1] == 512 && dims[2] == 256 && dims[3] == 128;
     for (int i = 0; i < 4; i++) {
         int in_t = p->tiles[i], out_t = (i < 3) ? p->tiles[i + 1] : 1;
         size_t nw = (size_t)out_t * in_t * 4 * 64, nb = (size_t)out_t * 4 * 64;
@@ -2261,13 +2279,35 @@ int lg_policy_create(const int32_t dims[5], const float *const weights[4], const
     if (hipMalloc(&p->d_std, 16 * 4) != hipSuccess || hipMemcpy(p->d_std, std, dims[4] * 4, hipMemcpyHostToDevice) != hipSuccess) {
         lg_policy_destroy(p); return fail(-10, "policy std upload failed");
     }
+    if (p->wide) {                                                 // split-bf16 operand stream: raw parameters up, packed on the device
+        float *raw_w[4] = {nullptr, nullptr, nullptr, nullptr}, *raw_b[4] = {nullptr, nullptr, nullptr, nullptr};
+        bool ok = true;
+        for (int i = 0; i < 4 && ok; i++) {
+            p->wide_ks[i] = i == 0 ? (dims[0] + 15) / 16 : dims[i] / 16;
+            p->wide_ot[i] = (dims[i + 1] + 31) / 32;
+            const size_t nw = (size_t)dims[i] * dims[i + 1], nb = (size_t)dims[i + 1];
+            ok = hipMalloc(&p->d_wb[i], (size_t)p->wide_ot[i] * p->wide_ks[i] * 1024 * sizeof(__bf16)) == hipSuccess &&
+                 hipMalloc(&p->d_bb[i], (size_t)p->wide_ot[i] * 32 * 4) == hipSuccess &&
+                 hipMalloc(&raw_w[i], nw * 4) == hipSuccess && hipMalloc(&raw_b[i], nb * 4) == hipSuccess &&
+                 hipMemcpy(raw_w[i], weights[i], nw * 4, hipMemcpyHostToDevice) == hipSuccess &&
+                 hipMemcpy(raw_b[i], biases[i], nb * 4, hipMemcpyHostToDevice) == hipSuccess;
+        }
+        if (ok) ok = policy_pack_wide(p, raw_w, raw_b, nullptr) == 0 && hipStreamSynchronize(nullptr) == hipSuccess;
+        for (int i = 0; i < 4; i++) { if (raw_w[i]) (void)hipFree(raw_w[i]); if (raw_b[i]) (void)hipFree(raw_b[i]); }
+        if (!ok) { lg_policy_destroy(p); return fail(-10, "wide policy weight upload failed"); }
+    }
     *out = p;
     return 0;
 }
 
 void lg_policy_destroy(lg_policy *p) {
     if (!p) return;
-    for (int i = 0; i < 4; i++) { if (p->d_w[i]) (void)hipFree(p->d_w[i]); if (p->d_b[i]) (void)hipFree(p->d_b[i]); }
+    for (int i = 0; i < 4; i++) {
+        if (p->d_w[i]) (void)hipFree(p->d_w[i]);
+        if (p->d_b[i]) (void)hipFree(p->d_b[i]);
+        if (p->d_wb[i]) (void)hipFree(p->d_wb[i]);
+        if (p->d_bb[i]) (void)hipFree(p->d_bb[i]);
+    }
     if (p->d_std) (void)hipFree(p->d_std);
     delete p;
 }
@@ -2288,6 +2328,15 @@ int lg_policy_act(lg_policy *p, const float *obs, float *actions, float *mean, i
     dim3 g((num_envs + 15) / 16), b(64 * LG_POLICY_WAVES);
     hipStream_t st = (hipStream_t)stream;
     const int t0 = p->tiles[0], t1 = p->tiles[1], t2 = p->tiles[2], t3 = p->tiles[3];
+    if (p->wide && g_wide_precision == 1 && (t0 == 15 || t0 == 11)) {          // 32 envs per workgroup on the bf16 matrix cores
+        lg::PolicyWideArgs w; w.base = a;
+        for (int i = 0; i < 4; i++) { w.wb[i] = reinterpret_cast<const lg::bf16x8g *>(p->d_wb[i]); w.bb[i] = p->d_bb[i]; }
+        dim3 gw((num_envs + LG_PW_ENVS - 1) / LG_PW_ENVS), bw(64 * LG_PW_WAVES);
+        if (t0 == 15) hipLaunchKernelGGL((lg::k_policy_act_wide<15, 16, 8, 4>), gw, bw, 0, st, w);     // rough: 235-512-256-128
+        else hipLaunchKernelGGL((lg::k_policy_act_wide<11, 16, 8, 4>), gw, bw, 0, st, w);              // cassie: 169-512-256-128
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     if (t0 == 3 && t1 == 8 && t2 == 4 && t3 == 2) hipLaunchKernelGGL((k_policy_act<3, 8, 4, 2>), g, b, 0, st, a);            // flat: 48-128-64-32
     else if (t0 == 15 && t1 == 32 && t2 == 16 && t3 == 8) hipLaunchKernelGGL((k_policy_act<15, 32, 16, 8>), g, b, 0, st, a);  // rough: 235-512-256-128
     else if (t0 == 11 && t1 == 32 && t2 == 16 && t3 == 8) hipLaunchKernelGGL((k_policy_act<11, 32, 16, 8>), g, b, 0, st, a);  // cassie: 169-512-256-128

@@ -129,4 +129,189 @@ __global__ void __launch_bounds__(64 * LG_POLICY_WAVES) k_policy_act(const Polic
     policy_forward<D0T, D1T, D2T, D3T>(A, xa, xb, xy, blockIdx.x, threadIdx.x >> 6, threadIdx.x & 63, step, nullptr);
 }
 
+// ------------------------------------------------------------------ wide actors (235/169-512-256-128-12): split-bf16 build
+// The f32 kernel above is bound by the f32 MFMA rate (4512 v_mfma_f32_16x16x4_f32 per 16 envs = 15 us of matrix-core time per
+// workgroup) and streams the 1.1 MB of weights once per 16 envs.  This build works on 32 envs per workgroup with
+// v_mfma_f32_32x32x16_bf16 (16 x the f32 rate): every f32 operand x is split into hi = bf16(x), lo = bf16(x - hi) and each
+// product is formed as lo*hi + hi*lo + hi*hi with f32 accumulation (the dropped lo*lo term is 2^-16 relative) -- the same
+// arithmetic as k_gemm_wide_bf16x3 (lg_gemm.h), selected by the same switch (lg_mlp_wide_set_precision).
+//   D[out 32][env 32] += W[out][k 16] * X[k][env]
+//   A (weights):      lane l holds W[32o + (l&31)][k = 8(l>>5) + 0..7]      -- pre-split and packed on the device (k_policy_pack_wide),
+//                     one coalesced 1-KB global_load_dwordx4 per operand, straight into registers: each weight is used by ONE wave
+//   B (activations):  lane l holds X[k = 8(l>>5) + 0..7][env l&31]          -- LDS, [k-step][hi/lo][lane] 16-byte entries
+//   D:                lane l, register i holds row 8(i>>2) + 4(l>>5) + (i&3) of column env l&31
+// so registers 8jj..8jj+7 of output tile o are exactly the B operand of the next layer's k-step 2o + jj when that layer's K
+// dimension is enumerated as  k-step (o, jj), lane half h, element (j', r) -> feature 32o + 8(2jj + j') + 4h + r.
+// The pack kernel permutes the weight columns accordingly: the LDS exchange needs no transposes.
+typedef __bf16 bf16x8g __attribute__((ext_vector_type(8)));
+typedef float f32x16p __attribute__((ext_vector_type(16)));
+#define LG_PW_ENVS 32
+#define LG_PW_WAVES 8                  // two waves per SIMD: one wave's epilogue / LDS traffic hides under the other's MFMAs
+#define LG_PW_INFLIGHT 32              // 1-KB weight loads a wave keeps in flight: the stream is L2-LATENCY bound (measured: 16 loads in
+                                       // flight per wave on 4 waves = 18 B/clk/CU of the ~64 the L2 delivers), so 8 x 32 KB per CU
+
+struct PolicyWideArgs {
+    PolicyArgs base;
+    const bf16x8g *wb[4];  // [out tile][k-step][hi/lo][lane] (k_policy_pack_wide)
+    const float *bb[4];    // biases, padded to 32 * out tiles
+};
+
+LG_DEV void split8(const float (&v)[8], bf16x8g &hi, bf16x8g &lo) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) { hi[i] = (__bf16)v[i]; lo[i] = (__bf16)(v[i] - (float)hi[i]); }
+}
+
+// The weight stream of one wave through one layer: KS k-steps x TPW output tiles, a ring of PF k-steps of operands in registers.
+// Workgroups walk the k-steps from different starting points (rot) so that the chip does not ask the L2 for the same lines at once.
+template <int KS, int TPW> struct WideStream {
+    static constexpr int PF = (LG_PW_INFLIGHT / (2 * TPW) + 1) < KS + 1 ? (LG_PW_INFLIGHT / (2 * TPW) + 1) : KS + 1;     // ring slots; PF - 1 k-steps ahead
+    bf16x8g wh[PF][TPW], wl[PF][TPW];
+    LG_DEV void fetch(const bf16x8g *__restrict__ w, int o0, int rot, int lane, int s) {
+        int sr = s + rot; sr = sr >= KS ? sr - KS : sr;
+#pragma unroll
+        for (int t = 0; t < TPW; t++) {
+            const bf16x8g *q = w + ((size_t)((o0 + t) * KS + sr) * 2) * 64 + lane;
+            wh[s % PF][t] = q[0]; wl[s % PF][t] = q[64];
+        }
+    }
+    LG_DEV void prime(const bf16x8g *__restrict__ w, int o0, int rot, int lane) {
+#pragma unroll
+        for (int s = 0; s < PF - 1; s++) if (s < KS) fetch(w, o0, rot, lane, s);
+    }
+    LG_DEV void run(const bf16x8g *__restrict__ w, const bf16x8g (*xin)[2][64], int o0, int rot, int lane, f32x16p (&acc)[TPW]) {
+#pragma unroll
+        for (int t = 0; t < TPW; t++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[t][i] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+            if (s + PF - 1 < KS) fetch(w, o0, rot, lane, s + PF - 1);
+            int sr = s + rot; sr = sr >= KS ? sr - KS : sr;
+            const bf16x8g bh = xin[sr][0][lane], bl = xin[sr][1][lane];
+#pragma unroll
+            for (int t = 0; t < TPW; t++) {
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[s % PF][t], bh, acc[t], 0, 0, 0);     // small terms first
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[s % PF][t], bl, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[s % PF][t], bh, acc[t], 0, 0, 0);
+            }
+        }
+    }
+};
+
+// bias + ELU + split of TPW finished tiles -> the next layer's k-steps 2o, 2o + 1 in LDS
+template <int TPW>
+LG_DEV void wide_epilogue(const f32x16p (&acc)[TPW], const float *__restrict__ b, bf16x8g (*xout)[2][64], int o0, int lane) {
+    const int h = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < TPW; t++) {
+        const float *bo = b + 32 * (o0 + t) + 4 * h;
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = elu1(acc[t][8 * jj + i] + bo[8 * (2 * jj + (i >> 2)) + (i & 3)]);
+            bf16x8g hi, lo;
+            split8(v, hi, lo);
+            xout[2 * (o0 + t) + jj][0][lane] = hi; xout[2 * (o0 + t) + jj][1][lane] = lo;
+        }
+    }
+}
+
+// K0S = ceil(num_obs / 16) k-steps of layer 0; H1T/H2T/H3T = hidden widths / 32.  Every wave's weight stream runs ahead of the
+// layer barriers: the ring of layer l+1 is primed before layer l's epilogue, so no layer starts with an empty pipeline.
+template <int K0S, int H1T, int H2T, int H3T>
+__global__ void __launch_bounds__(64 * LG_PW_WAVES) k_policy_act_wide(const PolicyWideArgs W) {
+    const PolicyArgs &A = W.base;
+    constexpr int NW = LG_PW_WAVES;
+    static_assert(H1T % NW == 0 && (H2T % NW == 0 || H2T <= NW) && H3T <= NW, "tiles per wave");
+    constexpr int T1 = H1T / NW, T2 = H2T >= NW ? H2T / NW : 1, T3 = 1;
+    constexpr int KA = K0S > 2 * H2T ? K0S : 2 * H2T, KB = H1T > H3T ? 2 * H1T : 2 * H3T;
+    __shared__ bf16x8g xa[KA][2][64], xb[KB][2][64];               // ping-pong activations: obs / x2 in xa, x1 / x3 in xb (96 KB)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5;
+    const int wv = (wave + blockIdx.x) % NW;                       // which share of the output tiles this wave takes (rotates over workgroups)
+    const int r0 = (blockIdx.x * 5) % K0S, r1 = (blockIdx.x * 5) % (2 * H1T), r2 = (blockIdx.x * 5) % (2 * H2T);
+    const bool on2 = wv * T2 < H2T, on3 = wv * T3 < H3T;
+    WideStream<K0S, T1> s1;
+    s1.prime(W.wb[0], wv * T1, r0, lane);
+    const int64_t step = A.step >= 0 ? A.step : (A.step_counter ? A.step_counter[0] + 1 : 0);
+    int env = blockIdx.x * LG_PW_ENVS + (lane & 31);
+    const bool live = env < A.num_envs;
+    if (!live) env = A.num_envs - 1;
+    const float *o = A.obs + (size_t)env * A.num_obs;
+    for (int s = wave; s < K0S; s += NW) {                         // layer-0 B operands from global, natural k order
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) { const int k = 16 * s + 8 * h + i; v[i] = k < A.num_obs ? o[k] : 0.0f; }
+        bf16x8g hi, lo;
+        split8(v, hi, lo);
+        xa[s][0][lane] = hi; xa[s][1][lane] = lo;
+    }
+    __syncthreads();
+    f32x16p a1[T1];
+    s1.run(W.wb[0], xa, wv * T1, r0, lane, a1);
+    WideStream<2 * H1T, T2> s2;
+    if (on2) s2.prime(W.wb[1], wv * T2, r1, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    wide_epilogue<T1>(a1, W.bb[0], xb, wv * T1, lane);
+    __syncthreads();
+    f32x16p a2[T2];
+    WideStream<2 * H2T, T3> s3;
+    if (on2) s2.run(W.wb[1], xb, wv * T2, r1, lane, a2);
+    if (on3) s3.prime(W.wb[2], wv * T3, r2, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    if (on2) wide_epilogue<T2>(a2, W.bb[1], xa, wv * T2, lane);
+    __syncthreads();
+    f32x16p a3[T3];
+    WideStream<2 * H3T, 1> s4;
+    if (on3) s3.run(W.wb[2], xa, wv * T3, r2, lane, a3);
+    if (wave == 0) s4.prime(W.wb[3], 0, 0, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    if (on3) wide_epilogue<T3>(a3, W.bb[2], xb, wv * T3, lane);
+    __syncthreads();
+    if (wave != 0) return;
+    f32x16p y[1];
+    s4.run(W.wb[3], xb, 0, 0, lane, y);
+    // lane (env, h), register i = 4ii + r (ii = 0, 1): action a = 8ii + 4h + r, i.e. group g = a >> 2 = 2ii + h of the f32 kernel's
+    // noise stream (rand4 sub-stream 100 + g): same samples from both builds for the same mean
+#pragma unroll
+    for (int ii = 0; ii < 2; ii++) {
+        const int g = 2 * ii + h;
+        if (4 * g >= A.num_actions) continue;
+        float u[4];
+        rand4(A.seed ^ 0x9E3779B97F4A7C15ull, env, step, 100 + g, 0, u);
+        const float rad0 = sqrtf(-2.0f * __logf(fmaxf(u[0], 1e-12f))), rad1 = sqrtf(-2.0f * __logf(fmaxf(u[2], 1e-12f)));
+        float s0, c0, sn1, c1;
+        __sincosf(6.2831853f * u[1], &s0, &c0);
+        __sincosf(6.2831853f * u[3], &sn1, &c1);
+        const float eps[4] = {rad0 * c0, rad0 * s0, rad1 * c1, rad1 * sn1};
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int a = 4 * g + r;
+            if (a < A.num_actions && live) {
+                const float m = y[0][4 * ii + r] + W.bb[3][a], act = A.deterministic ? m : m + A.std[a] * eps[r];
+                if (A.mean) A.mean[(size_t)env * A.num_actions + a] = m;
+                A.actions[(size_t)env * A.num_actions + a] = act;
+            }
+        }
+    }
+}
+
+// torch Linear [out, in] f32 -> the operand stream above; `first` selects the natural k order of layer 0
+__global__ void k_policy_pack_wide(const float *__restrict__ Wt, const float *__restrict__ bias, int in_dim, int out_dim, int KS, int OT, int first,
+                                   __bf16 *__restrict__ wp, float *__restrict__ bp) {
+    const size_t n = (size_t)OT * KS * 64 * 8;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < n + (size_t)OT * 32; idx += (size_t)gridDim.x * blockDim.x) {
+        if (idx >= n) { const int r = (int)(idx - n); bp[r] = r < out_dim ? bias[r] : 0.0f; continue; }
+        const int i = (int)(idx & 7), l = (int)((idx >> 3) & 63);
+        const size_t os = idx >> 9;
+        const int s = (int)(os % KS), o = (int)(os / KS), hh = l >> 5;
+        const int row = 32 * o + (l & 31);
+        const int col = first ? 16 * s + 8 * hh + i : 32 * (s >> 1) + 8 * (2 * (s & 1) + (i >> 2)) + 4 * hh + (i & 3);
+        const float v = (row < out_dim && col < in_dim) ? Wt[(size_t)row * in_dim + col] : 0.0f;
+        const __bf16 hi = (__bf16)v, lo = (__bf16)(v - (float)hi);
+        wp[((((size_t)o * KS + s) * 2 + 0) * 64 + l) * 8 + i] = hi;
+        wp[((((size_t)o * KS + s) * 2 + 1) * 64 + l) * 8 + i] = lo;
+    }
+}
+
 }  // namespace lg

@@ -88,8 +88,21 @@ def test_bundled_runner_learns_a_few_iterations(tmp_path):
     assert policy(env.get_observations()).shape == (128, 12)
 
 
-def test_fused_actor_matches_torch_forward():
-    """lg_policy_act (fp32 MFMA) vs the plain PyTorch fp32 forward of the same ActorCritic, all three compiled-in shapes."""
+@pytest.mark.parametrize("precision", [1, 0])
+def test_fused_actor_matches_torch_forward(precision):
+    """lg_policy_act vs the plain PyTorch fp32 forward of the same ActorCritic, all three compiled-in shapes.  precision 0: the f32-MFMA
+    kernels (2e-5 of the output scale); precision 1 (the default): the wide shapes run k_policy_act_wide, split-bf16 products with
+    the lo*lo term dropped -- 16 significand bits per operand, tolerance 1e-4 of the output scale stated here."""
+    from legged_games_gym_amd import capi
+    from legged_games_gym_amd.rl import ActorCritic, FusedActor
+    old = capi.load_library().lg_mlp_wide_set_precision(precision)
+    try:
+        _fused_actor_cases(2e-5 if precision == 0 else 1e-4)
+    finally:
+        capi.load_library().lg_mlp_wide_set_precision(old)
+
+
+def _fused_actor_cases(tol):
     from legged_games_gym_amd.rl import ActorCritic, FusedActor
     for n_obs, hidden in ((48, [128, 64, 32]), (235, [512, 256, 128]), (169, [512, 256, 128])):
         torch.manual_seed(3)
@@ -97,25 +110,25 @@ def test_fused_actor_matches_torch_forward():
         with torch.no_grad():
             ac.std.copy_(torch.linspace(0.3, 1.4, 12))
         fa = FusedActor(ac, "cuda:0", seed=5)
-        obs = torch.randn(1000, n_obs, device="cuda") * 2.0            # 1000: not a multiple of 16 (tail wave)
+        obs = torch.randn(1000, n_obs, device="cuda") * 2.0            # 1000: not a multiple of 16 or 32 (tail lanes)
         with torch.no_grad():
             want = ac.actor(obs)
         actions, mean = fa.act_with_mean(obs)
         actions, mean = actions.clone(), mean.clone()          # the wrapper reuses its output buffers
         torch.cuda.synchronize()
         scale = float(want.abs().max())
-        assert float((mean - want).abs().max()) < 2e-5 * max(1.0, scale), (n_obs, float((mean - want).abs().max()))
+        assert float((mean - want).abs().max()) < tol * max(1.0, scale), (n_obs, float((mean - want).abs().max()))
         z = ((actions - mean) / ac.std.detach()).flatten()
         assert abs(float(z.mean())) < 0.03 and abs(float(z.std()) - 1.0) < 0.03 and float(z.abs().max()) < 6.0
         a2 = fa.act(obs).clone()
         assert not torch.equal(a2, actions)                            # fresh noise per call
-        assert torch.allclose(fa.act_inference(obs), want, atol=2e-5 * max(1.0, scale))
+        assert torch.allclose(fa.act_inference(obs), want, atol=tol * max(1.0, scale))
         with torch.no_grad():                                          # sync() re-uploads changed weights
             ac.actor[0].weight.mul_(0.5)
         fa.sync()
         with torch.no_grad():
             want2 = ac.actor(obs)
-        assert torch.allclose(fa.act_inference(obs), want2, atol=2e-5 * max(1.0, float(want2.abs().max())))
+        assert torch.allclose(fa.act_inference(obs), want2, atol=tol * max(1.0, float(want2.abs().max())))
 
 
 def test_fused_actor_follows_the_optimiser_through_the_device_repack():
@@ -134,7 +147,7 @@ def test_fused_actor_follows_the_optimiser_through_the_device_repack():
         obs = torch.randn(333, n_obs, device="cuda")
         got = fa.act_inference(obs).clone()
         want = ac.act_inference(obs).detach()
-        assert float((got - want).abs().max()) < 2e-5 * max(1.0, float(want.abs().max()))
+        assert float((got - want).abs().max()) < (2e-5 if n_obs == 48 else 1e-4) * max(1.0, float(want.abs().max()))
         fb = FusedActor(ac, "cuda:0", seed=1)                 # host-side pack of the same parameters
         assert torch.equal(fb.act_inference(obs), got)
         a1, m1 = fa.act_with_mean(obs); a1 = a1.clone()
