@@ -88,32 +88,43 @@ struct KArgs {                 // passed by value: lives in the kernarg segment 
 
 // ------------------------------------------------------------------ section profiler (debug builds: -DLG_PROFILE)
 #define LG_NPROF 20
+#define LG_NPROF_BLOCKS 1024
+#define LG_NPROF_TOTAL (LG_NPROF + LG_NPROF_BLOCKS * 40)
 #ifdef LG_PROFILE
 // lane 0 of each workgroup accumulates s_memtime deltas per section in LDS and adds them to A.prof at the end.
 // idx < 0 starts the clock; slot 14 = whole kernel (s_memtime), slot 15 = whole kernel on the 100 MHz wall clock.
-__device__ __forceinline__ void lg_prof(int idx, unsigned long long *out) {
+__device__ __forceinline__ void lg_prof(int idx, unsigned long long *out, unsigned long long note = 0) {
     __shared__ unsigned long long acc[LG_NPROF], prev, t0, w0;
     __builtin_amdgcn_sched_barrier(0);
     unsigned long long t = __builtin_readcyclecounter();
     if (threadIdx.x == 0) {
         if (idx < 0) { for (int i = 0; i < LG_NPROF; i++) acc[i] = 0; t0 = t; w0 = wall_clock64(); }
+        else if (idx >= 18) { acc[idx] = note; t = prev; }           // user slots 18, 19: a value, not a time; the clock is not advanced
         else acc[idx] += t - prev;
         if (out) {
             acc[14] = t - t0; acc[15] = wall_clock64() - w0;
-            for (int i = 0; i < 16; i++) atomicAdd(out + i, acc[i]);
-            atomicMax(out + 16, acc[14]);                        // slowest workgroup of any launch since the last reset
+            // per workgroup, plain stores to its own record (atomics on shared accumulators stall the workgroups still running):
+            // [0] running sums over the launches since the last reset, [1] the LAST launch; slots 16/17 = start/end on the wall clock
+            if (blockIdx.x < LG_NPROF_BLOCKS) {
+                unsigned long long *a = out + LG_NPROF + (size_t)blockIdx.x * 40, *b = a + 20;
+                for (int i = 0; i < 16; i++) { a[i] += acc[i]; b[i] = acc[i]; }
+                a[16] = a[16] > acc[14] ? a[16] : acc[14];       // slowest launch of this workgroup
+                b[16] = w0; b[17] = w0 + acc[15]; b[18] = acc[18]; b[19] = acc[19];
+            }
         }
-        prev = __builtin_readcyclecounter();
+        prev = idx >= 18 ? prev : __builtin_readcyclecounter();
     }
     __builtin_amdgcn_sched_barrier(0);
 }
 #define LG_PROF(i) lg_prof(i, nullptr)
 #define LG_PROF_BEGIN() lg_prof(-1, nullptr)
 #define LG_PROF_END(i, out) lg_prof(i, out)
+#define LG_PROF_NOTE(i, v) lg_prof(i, nullptr, v)
 #else
 #define LG_PROF(i)
 #define LG_PROF_BEGIN()
 #define LG_PROF_END(i, out)
+#define LG_PROF_NOTE(i, v)
 #endif
 enum { PF_PROLOGUE = 0, PF_TORQUE, PF_KINEMATICS, PF_INWARD, PF_BASE, PF_OUTWARD, PF_INTEGRATE, PF_POST, PF_EXTRAS,
        PF_POST_HEIGHTS, PF_POST_TERMS, PF_POST_REWARD, PF_POST_RESET, PF_POST_OBS };
@@ -801,15 +812,18 @@ template <int L> LG_DEV void pd_torques(const lg_params &P, const float *tab, co
 }
 
 // ------------------------------------------------------------------ commands / heights / reset values
-LG_DEV void resample_commands(const lg_params &P, int e, int64_t step, int purpose, float (&cmd)[4]) {   // :347-369
-    float u[4];
-    rand4(P.seed, e, step, purpose, 0, u);
+LG_DEV void resample_commands_u(const lg_params &P, const float (&u)[4], float (&cmd)[4]) {   // :347-369, from four uniforms
     cmd[0] = urange(P.cmd_lin_vel_x[0], P.cmd_lin_vel_x[1], u[0]);
     cmd[1] = urange(P.cmd_lin_vel_y[0], P.cmd_lin_vel_y[1], u[1]);
     if (P.heading_command) cmd[3] = urange(P.cmd_heading[0], P.cmd_heading[1], u[2]);
     else cmd[2] = urange(P.cmd_ang_vel_yaw[0], P.cmd_ang_vel_yaw[1], u[2]);
     float keep = (sqrtf(cmd[0] * cmd[0] + cmd[1] * cmd[1]) > 0.2f) ? 1.0f : 0.0f;
     cmd[0] *= keep; cmd[1] *= keep;
+}
+LG_DEV void resample_commands(const lg_params &P, int e, int64_t step, int purpose, float (&cmd)[4]) {
+    float u[4];
+    rand4(P.seed, e, step, purpose, 0, u);
+    resample_commands_u(P, u, cmd);
 }
 LG_DEV float wrap_to_pi(float a) {                                                                       // utils/math.py:45-48
     const float two_pi = 6.2831855f, pi = 3.14159274f;
@@ -897,14 +911,39 @@ template <class T, int NW = LG_STEP_WAVES> struct HeightCrew {
     }
 };
 
+// The uniforms of a reset (Philox blocks keyed by env / step / purpose: ~0.27 us each on a lone wave) do not depend on the
+// state: in the multi-wave kernels the last helper wave draws them for EVERY lane while it waits for the first sub-step
+// (ResetRand::draw), and the rigid-body wave only reads the ones it needs -- a workgroup with a reset env no longer runs
+// 1.4 us behind the others (the kernel ends with its slowest workgroup).
+template <class T> struct ResetRand {
+    static constexpr int NB = (T::L + 2) / 4 + 1;                  // Philox blocks covering the limb's L consecutive dofs
+    enum { ROOT0 = NB, ROOT1, CMD, TERRAIN, SLOTS };
+    float4 u[SLOTS][LG_BLOCK];
+    LG_DEV void draw(const lg_params &P, int e, int k, int64_t step, int lane) {
+        float r[4];
+        const int b0 = (k * T::L) >> 2;
+#pragma unroll
+        for (int i = 0; i < NB; i++) { rand4(P.seed, e, step, RNG_DOF, b0 + i, r); u[i][lane] = make_float4(r[0], r[1], r[2], r[3]); }
+        rand4(P.seed, e, step, RNG_ROOT, 0, r); u[ROOT0][lane] = make_float4(r[0], r[1], r[2], r[3]);
+        rand4(P.seed, e, step, RNG_ROOT, 1, r); u[ROOT1][lane] = make_float4(r[0], r[1], r[2], r[3]);
+        rand4(P.seed, e, step, RNG_CMD_RESET, 0, r); u[CMD][lane] = make_float4(r[0], r[1], r[2], r[3]);
+        if (P.terrain_curriculum) { rand4(P.seed, e, step, RNG_TERRAIN, 0, r); u[TERRAIN][lane] = make_float4(r[0], r[1], r[2], r[3]); }
+    }
+};
+
 // New state of a reset environment (reset_idx :147-191).  Every lane of the env computes the shared part
 // identically; `origin` is in/out (terrain curriculum :446-469), lane-0 writes are done by the caller.
 template <class T>
 LG_DEV void reset_values(const KArgs &A, const float *tab, int e, int k, int64_t step, float (&root)[13], float (&q)[T::L],
-                         float (&qd)[T::L], float (&cmd)[4], float (&origin)[3], int &level, bool &level_changed) {
+                         float (&qd)[T::L], float (&cmd)[4], float (&origin)[3], int &level, bool &level_changed,
+                         const ResetRand<T> *rr = nullptr, int lane = 0) {
     constexpr int L = T::L;
     const lg_params &P = A.P;
     float u[4], v[4];
+    auto uniforms = [&](int purpose, int block, int slot, float (&out)[4]) {
+        if (rr) { const float4 w = rr->u[slot][lane]; out[0] = w.x; out[1] = w.y; out[2] = w.z; out[3] = w.w; }
+        else rand4(P.seed, e, step, purpose, block, out);
+    };
     level_changed = false;
     if (P.terrain_curriculum && A.B.terrain_levels) {
         float dx = root[0] - origin[0], dy = root[1] - origin[1], dist = sqrtf(dx * dx + dy * dy);
@@ -912,7 +951,7 @@ LG_DEV void reset_values(const KArgs &A, const float *tab, int e, int k, int64_t
         int down = (dist < sqrtf(cmd[0] * cmd[0] + cmd[1] * cmd[1]) * P.max_episode_length_s * 0.5f) && !up;
         int lvl = A.B.terrain_levels[e] + up - down;
         if (lvl >= P.terrain_num_rows) {
-            rand4(P.seed, e, step, RNG_TERRAIN, 0, u);
+            uniforms(RNG_TERRAIN, 0, ResetRand<T>::TERRAIN, u);
             lvl = (int)(u[0] * P.terrain_num_rows);
             if (lvl >= P.terrain_num_rows) lvl = P.terrain_num_rows - 1;
         } else if (lvl < 0) lvl = 0;
@@ -920,23 +959,29 @@ LG_DEV void reset_values(const KArgs &A, const float *tab, int e, int k, int64_t
         const float *to = A.B.terrain_origins + ((size_t)lvl * P.terrain_num_cols + A.B.terrain_types[e]) * 3;
         origin[0] = to[0]; origin[1] = to[1]; origin[2] = to[2];
     }
+    const int b0 = (k * L) >> 2;
 #pragma unroll
     for (int j = 0; j < L; j++) {
         int d = k * L + j;
-        rand4(P.seed, e, step, RNG_DOF, d >> 2, u);
-        float uj = (d & 3) == 0 ? u[0] : ((d & 3) == 1 ? u[1] : ((d & 3) == 2 ? u[2] : u[3]));
+        float uj;
+        if (rr) uj = reinterpret_cast<const float *>(&rr->u[(d >> 2) - b0][lane])[d & 3];
+        else {
+            rand4(P.seed, e, step, RNG_DOF, d >> 2, u);
+            uj = (d & 3) == 0 ? u[0] : ((d & 3) == 1 ? u[1] : ((d & 3) == 2 ? u[2] : u[3]));
+        }
         q[j] = tab[j * LG_JS + J_Q0] * urange(0.5f, 1.5f, uj);
         qd[j] = 0.0f;
     }
 #pragma unroll
     for (int i = 0; i < 13; i++) root[i] = P.base_init_state[i];
     root[0] += origin[0]; root[1] += origin[1]; root[2] += origin[2];
-    rand4(P.seed, e, step, RNG_ROOT, 0, u); rand4(P.seed, e, step, RNG_ROOT, 1, v);
+    uniforms(RNG_ROOT, 0, ResetRand<T>::ROOT0, u); uniforms(RNG_ROOT, 1, ResetRand<T>::ROOT1, v);
     if (P.custom_origins) { root[0] += urange(-1.0f, 1.0f, u[0]); root[1] += urange(-1.0f, 1.0f, u[1]); }
     root[7] = urange(-0.5f, 0.5f, u[2]); root[8] = urange(-0.5f, 0.5f, u[3]);
     root[9] = urange(-0.5f, 0.5f, v[0]); root[10] = urange(-0.5f, 0.5f, v[1]);
     root[11] = urange(-0.5f, 0.5f, v[2]); root[12] = urange(-0.5f, 0.5f, v[3]);
-    resample_commands(P, e, step, RNG_CMD_RESET, cmd);
+    uniforms(RNG_CMD_RESET, 0, ResetRand<T>::CMD, u);
+    resample_commands_u(P, u, cmd);
 }
 
 // ------------------------------------------------------------------ observations (legged_robot.py:212-230, :100-101)
@@ -1058,7 +1103,7 @@ template <bool OFF, int L = 3> struct StepSharedT {              // LDS hand-ove
 // episode_sums[name] += term (:203); read + zeroed for reset envs, whose sums feed extras["episode"] (reset_idx :179-183).
 // Runs on a helper wave (one lane per env): off the rigid-body wave's critical path.
 struct EpisodeSums {
-    float sum[LG_NUM_REWARD_TERMS];
+    float sum[LG_NUM_REWARD_TERMS] = {};
     LG_DEV void load(const KArgs &A, int e) {                     // issued early: the running sums do not depend on this step
 #pragma unroll
         for (int t = 0; t < LG_NUM_REWARD_TERMS; t++) {
@@ -1066,25 +1111,35 @@ struct EpisodeSums {
             sum[t] = slot >= 0 ? A.B.episode_sums[(size_t)slot * A.P.num_envs + e] : 0.0f;
         }
     }
-    template <class SH> LG_DEV void update(const KArgs &A, int e, int lane, const SH &sh) {
+    // keep == this lane keeps an env's sums.  The finished episodes of the workgroup leave as ONE wave instruction: the keeper lanes
+    // park their sums in sh.r_t (this wave has consumed it), lane t adds term t over the reset envs and issues the atomic for its
+    // slot -- 18 single-lane atomics to one 128-byte line took ~3 us to drain (measured: workgroups with a reset env ended 3 us
+    // later in the ticket section), and the kernel ends with its slowest workgroup.
+    template <int K, class SH> LG_DEV void update(const KArgs &A, int e, int lane, SH &sh, bool keep) {
         const lg_params &P = A.P;
-        const bool reset = sh.rst[lane] != 0;
-#pragma unroll
-        for (int t = 0; t < LG_NUM_REWARD_TERMS; t++) {
-            const int slot = P.reward_slot[t];
-            if (slot >= 0) {
-                sum[t] += sh.r_t[t][lane];
-                A.B.episode_sums[(size_t)slot * P.num_envs + e] = reset ? 0.0f : sum[t];
-            }
-        }
-        if (reset) {
+        const bool reset = keep && sh.rst[lane] != 0;
+        if (keep) {
 #pragma unroll
             for (int t = 0; t < LG_NUM_REWARD_TERMS; t++) {
                 const int slot = P.reward_slot[t];
-                if (slot >= 0) atomicAdd(A.B.extras_accum + slot, sum[t]);
+                if (slot >= 0) {
+                    sum[t] += sh.r_t[t][lane];
+                    A.B.episode_sums[(size_t)slot * P.num_envs + e] = reset ? 0.0f : sum[t];
+                }
             }
-            atomicAdd(A.B.extras_accum + P.num_reward_slots, 1.0f);
         }
+        const unsigned long long finished = __ballot(reset);
+        if (finished == 0) return;                                 // wave-uniform
+#pragma unroll
+        for (int t = 0; t < LG_NUM_REWARD_TERMS; t++) sh.r_t[t][lane] = reset ? sum[t] : 0.0f;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < LG_NUM_REWARD_TERMS) {
+            const int slot = P.reward_slot[lane];
+            float tot = 0.0f;
+            for (int i = 0; i < LG_BLOCK; i += K) tot += sh.r_t[lane][i];
+            if (slot >= 0) atomicAdd(A.B.extras_accum + slot, tot);
+        } else if (lane == LG_NUM_REWARD_TERMS) atomicAdd(A.B.extras_accum + P.num_reward_slots, (float)__popcll(finished));
     }
 };
 
@@ -1094,7 +1149,7 @@ template <class T, bool NET, bool HF, int NW, bool SC = false> struct HelperWave
                                                                  // wave w takes bodies w-1, w-1 + (NW-1), ...
     static LG_DEV void run(const KArgs &A, int wave, int lane, int e, int k, int d0, bool live, int64_t step, const float *tab,
                            float2 (*lds_x)[LG_BLOCK], float (*lds_tau)[LG_BLOCK], StepSharedT<OFF, T::L> &sh, SelfLds<T> *sc = nullptr,
-                           const float *lds_tab = nullptr) {
+                           const float *lds_tab = nullptr, ResetRand<T> *reset_rand = nullptr) {
         const lg_buffers &B = A.B;
         const lg_params &P = A.P;
         const int j = wave - 1;
@@ -1114,6 +1169,7 @@ template <class T, bool NET, bool HF, int NW, bool SC = false> struct HelperWave
                 lstm_split(u, part[a][0], part[a][1]);
             }
         }
+        if (wave == NW - 1) reset_rand->draw(P, e, k, step, lane);      // in the shadow of the rigid-body wave's prologue; published by the barriers below
         if (NET || OFF) {
             for (int it = 0; it < P.decimation; it++) {
                 __syncthreads();                                   // this sub-step has started: actuator inputs are in lds_x
@@ -1161,7 +1217,7 @@ template <class T, bool NET, bool HF, int NW, bool SC = false> struct HelperWave
         EpisodeSums es;
         if (keeper) es.load(A, e);
         __syncthreads();                                           // P3: reset flags / post-reset root z / reward terms published
-        if (keeper) es.update(A, e, lane, sh);
+        if (wave == 1) es.template update<T::K>(A, e, lane, sh, keeper);
         if (P.measure_heights) hc.write_obs(A, e, k + T::K * wave, live, step, sh.root_z[lane]);
         if (NET) {
             const bool reset = sh.rst[lane] != 0;
@@ -1204,6 +1260,7 @@ __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
     constexpr bool OFF = NW >= 2;
     __shared__ StepSharedT<OFF, L> sh;
     __shared__ SelfStore<SC, T> sc_store;
+    __shared__ ResetRand<T> reset_rand;                         // NW > 1: a reset's uniforms for every lane, drawn by the last helper wave
     __shared__ int s_last;
     __shared__ float4 pol_xa[POL ? 4 : 1][64], pol_xb[POL ? 8 : 1][64], pol_xy[1][64];
     __shared__ float lds_act[POL ? 16 : 1][16];                 // sampled actions [action][env in block]
@@ -1228,7 +1285,7 @@ __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
         __syncthreads();
     }
     if (wave > 0) {
-        HelperWave<T, NET, HF, NW, SC>::run(A, wave, lane, e, k, d0, live, step, tab, lds_x, lds_tau, sh, sc_store.get(), lds_tab);
+        HelperWave<T, NET, HF, NW, SC>::run(A, wave, lane, e, k, d0, live, step, tab, lds_x, lds_tau, sh, sc_store.get(), lds_tab, &reset_rand);
     } else {
     // ---- load persistent state (read once per env-step)
     float root[13], q[L], qd[L], act[L], tau[L];
@@ -1430,7 +1487,7 @@ __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
     float origin[3] = {B.env_origins[(size_t)e * 3], B.env_origins[(size_t)e * 3 + 1], B.env_origins[(size_t)e * 3 + 2]};
     if (reset) {
         int level = 0; bool level_changed = false;
-        reset_values<T>(A, tab, e, k, step, root, q, qd, cmd, origin, level, level_changed);
+        reset_values<T>(A, tab, e, k, step, root, q, qd, cmd, origin, level, level_changed, NW > 1 ? &reset_rand : nullptr, lane);
         if (writer && level_changed) {
             __hip_atomic_store(B.terrain_levels + e, level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // read by the finisher
             B.env_origins[(size_t)e * 3] = origin[0]; B.env_origins[(size_t)e * 3 + 1] = origin[1]; B.env_origins[(size_t)e * 3 + 2] = origin[2];
@@ -1440,9 +1497,12 @@ __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
 
     sh.rst[lane] = reset ? 1 : 0; sh.root_z[lane] = root[2];
     __syncthreads();                                               // P3: helpers write the height observations / actuator state
-    if (NW == 1 && live && k == 0) { EpisodeSums es; es.load(A, e); es.update(A, e, lane, sh); }   // no helper wave: keep the sums here
+    if (NW == 1) { EpisodeSums es; const bool keep = live && k == 0; if (keep) es.load(A, e); es.template update<K>(A, e, lane, sh, keep); }   // no helper wave: keep the sums here
 
     LG_PROF(PF_POST_RESET);
+#ifdef LG_PROFILE
+    { int nr = 0; for (int i = 0; i < LG_BLOCK; i += K) nr += sh.rst[i]; LG_PROF_NOTE(18, (unsigned long long)nr); }
+#endif
     // compute_observations :130 (stale base-frame quantities for reset envs, as in the reference)
     write_observations<T>(A, e, k, live, step, root, q, qd, act, tab, blv, bav, pg, cmd, false);
     if (P.measure_heights) hc.write_obs(A, e, k, live, step, root[2]);
@@ -2478,8 +2538,23 @@ int lg_abi_version(void) { return LG_ABI_VERSION; }
 int lg_debug_profile(lg_sim *s, unsigned long long *out16 /* [LG_NPROF] */, int reset) {
     if (!s || !s->d_prof) return -1;
     if (hipDeviceSynchronize() != hipSuccess) return -2;
-    if (hipMemcpy(out16, s->d_prof, sizeof(unsigned long long) * LG_NPROF, hipMemcpyDeviceToHost) != hipSuccess) return -2;
-    if (reset && hipMemset(s->d_prof, 0, sizeof(unsigned long long) * LG_NPROF) != hipSuccess) return -2;
+    std::vector<unsigned long long> h(LG_NPROF_TOTAL);
+    if (hipMemcpy(h.data(), s->d_prof, sizeof(unsigned long long) * LG_NPROF_TOTAL, hipMemcpyDeviceToHost) != hipSuccess) return -2;
+    for (int i = 0; i < LG_NPROF; i++) out16[i] = 0;
+    for (int b = 0; b < LG_NPROF_BLOCKS; b++) {
+        const unsigned long long *a = h.data() + LG_NPROF + (size_t)b * 40;
+        for (int i = 0; i < 16; i++) out16[i] += a[i];
+        if (a[16] > out16[16]) out16[16] = a[16];
+    }
+    if (reset && hipMemset(s->d_prof, 0, sizeof(unsigned long long) * LG_NPROF_TOTAL) != hipSuccess) return -2;
+    return 0;
+}
+// the last launch, per workgroup: out[blocks][20] = 16 section slots, start and end on the 100 MHz wall clock, two user slots
+int lg_debug_profile_blocks(lg_sim *s, unsigned long long *out, int blocks) {
+    if (!s || !s->d_prof || blocks < 0 || blocks > LG_NPROF_BLOCKS) return -1;
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    for (int b = 0; b < blocks; b++)
+        if (hipMemcpy(out + (size_t)b * 20, s->d_prof + LG_NPROF + (size_t)b * 40 + 20, sizeof(unsigned long long) * 20, hipMemcpyDeviceToHost) != hipSuccess) return -2;
     return 0;
 }
 #endif
@@ -2512,7 +2587,7 @@ int lg_create(const lg_params *params, const lg_robot_model *model, const float 
     memset(&s->B, 0, sizeof s->B);
     { hipDeviceProp_t prop; s->num_cus = (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256; }
 #ifdef LG_PROFILE
-    if (hipMalloc(&s->d_prof, sizeof(unsigned long long) * LG_NPROF) != hipSuccess || hipMemset(s->d_prof, 0, sizeof(unsigned long long) * LG_NPROF) != hipSuccess) { delete s; return fail(-10, "hipMalloc failed"); }
+    if (hipMalloc(&s->d_prof, sizeof(unsigned long long) * LG_NPROF_TOTAL) != hipSuccess || hipMemset(s->d_prof, 0, sizeof(unsigned long long) * LG_NPROF_TOTAL) != hipSuccess) { delete s; return fail(-10, "hipMalloc failed"); }
 #endif
     if (hipMalloc(&s->d_limb_table, sizeof(float) * (LG_MAX_LIMBS * (LG_MAX_CHAIN * LG_JS + 4 * LG_MAX_LIMB_POINTS + 1) + 2 * LG_MAX_HEIGHT_POINTS)) != hipSuccess) { delete s; return fail(-10, "hipMalloc failed"); }
     if (s->has_net) {

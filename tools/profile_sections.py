@@ -57,3 +57,30 @@ for i, name in enumerate(NAMES):
     print(f"  {name:45s} {c:9.0f} cyc  {c / tot * 100:5.1f} %  {c / tot * wall / 1e3:6.2f} us")
 print(f"  slowest workgroup of any launch: {v[16]} cycles = {v[16] / (tot / wall) / 1e3:.1f} us (the kernel ends when it does)")
 print(f"  {'(unattributed)':45s} {tot - sum(v[:14]) / wgs:9.0f} cyc")
+
+# ---- the last launch, workgroup by workgroup: which sections differ between workgroups, and when each one started / ended
+import numpy as np
+nb = min(1024, (env.num_envs * (2 if task == "cassie" else 4) + 63) // 64)
+lib.lg_debug_profile_blocks.argtypes, lib.lg_debug_profile_blocks.restype = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int], ctypes.c_int
+blk = (ctypes.c_uint64 * (20 * nb))()
+assert lib.lg_debug_profile_blocks(handle, blk, nb) == 0
+B = np.array(list(blk), dtype=np.float64).reshape(nb, 20)
+ghz = tot / wall
+print(f"last launch, {nb} workgroups: total per workgroup min {B[:, 14].min() / ghz / 1e3:.1f}  median {np.median(B[:, 14]) / ghz / 1e3:.1f}  p90 {np.quantile(B[:, 14], 0.9) / ghz / 1e3:.1f}  max {B[:, 14].max() / ghz / 1e3:.1f} us")
+start = (B[:, 16] - B[:, 16].min()) * 10.0 / 1e3; end = (B[:, 17] - B[:, 16].min()) * 10.0 / 1e3
+print(f"  start skew: median {np.median(start):.2f} max {start.max():.2f} us;  last end {end.max():.1f} us;  median end {np.median(end):.1f} us")
+slow = np.argsort(B[:, 14])[-max(1, nb // 20):]
+for i, name in enumerate(NAMES):
+    print(f"  {name:45s} median {np.median(B[:, i]) / ghz / 1e3:6.2f}  p90 {np.quantile(B[:, i], 0.9) / ghz / 1e3:6.2f}  max {B[:, i].max() / ghz / 1e3:6.2f}  | slowest 5% of workgroups: {B[slow, i].mean() / ghz / 1e3:6.2f} us")
+print("  slowest workgroups (blockIdx: total us, start us):", [(int(b), round(B[b, 14] / ghz / 1e3, 1), round(float(start[b]), 1)) for b in slow[-8:]])
+nr = B[:, 18]
+print(f"  resets in the launch: {int(nr.sum())} envs in {int((nr > 0).sum())} workgroups;  total us with resets {B[nr > 0, 14].mean() / ghz / 1e3 if (nr > 0).any() else 0:.1f}  without {B[nr == 0, 14].mean() / ghz / 1e3:.1f};  corr(total, resets) {np.corrcoef(B[:, 14], nr)[0, 1]:.2f}")
+print("  XCD (blockIdx % 8) mean total us:", [round(B[np.arange(nb) % 8 == x, 14].mean() / ghz / 1e3, 1) for x in range(8)])
+if (nr > 0).any():
+    print("  per section, workgroups WITH a reset env vs without (mean us):")
+    for i, name in enumerate(NAMES):
+        a, b = B[nr > 0, i].mean() / ghz / 1e3, B[nr == 0, i].mean() / ghz / 1e3
+        print(f"    {name:45s} {a:6.2f}  {b:6.2f}   {a - b:+6.2f}")
+    print("  rows of the workgroups with resets (us per section 0..13 | total | resets):")
+    for b in np.nonzero(nr > 0)[0][:24]:
+        print("   ", int(b), " ".join(f"{B[b, i] / ghz / 1e3:5.1f}" for i in range(14)), "|", f"{B[b, 14] / ghz / 1e3:5.1f}", "|", int(nr[b]))
