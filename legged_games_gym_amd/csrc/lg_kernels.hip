@@ -324,6 +324,8 @@ template <class T> struct SelfLds {
     float4 basepose[5][LG_BLOCK];        // rows of the base rotation, base angular and linear velocity (of the lane's env)
     float4 rec[T::K][T::NGRP][LG_SC_REC][LG_BLOCK];   // deepest contact of body g of this lane's limb with partner m (0: base; m: limb k ^ m); coef < 0: none
     alignas(16) int ready[LG_STEP_WAVES];   // helper wave w: sub-step number once its records are complete
+    float4 base_pts[LG_MAX_BASE_POINTS];    // A.base.pts, staged once: the detection loops index them with run-time counters, and a run-time
+                                            // index into the by-value kernel arguments can make hipcc copy all 3 KB of KArgs to scratch (95 vs 59 us)
 };
 LG_DEV V3 xyz(float4 a) { return v3(a.x, a.y, a.z); }
 // closest points of two segments, parameters in [0,1] (Ericson, RTCD 5.1.9); SA / SB: that "segment" is a point (compile time)
@@ -387,7 +389,7 @@ LG_DEV void self_detect(const KArgs &A, const float *lds_tab, int ln, int m, Sel
     }
     auto base_end = [&](int c, int e) {            // end point e of base capsule c (points come in equal-radius pairs; checked at lg_create)
         const int i0 = 2 * c, i = (e && i0 + 1 < A.base.num_pts) ? i0 + 1 : i0;
-        return mul(R0, v3(A.base.pts[i][0], A.base.pts[i][1], A.base.pts[i][2]));
+        return mul(R0, xyz(sc.base_pts[i]));
     };
     // ---- stage 1: which (my body, their body) bounding spheres touch?  bit ga * NGRP + gb (gb = 0 for the base)
     float4 gme[NGRP];
@@ -398,7 +400,7 @@ LG_DEV void self_detect(const KArgs &A, const float *lds_tab, int ln, int m, Sel
 #pragma unroll 1
         for (int c = 0; c < nbc; c++) {
             const V3 e0 = base_end(c, 0), d = base_end(c, 1) - e0;
-            const float dd = dot(d, d), rdd = dd > 0.0f ? 1.0f / dd : 0.0f, rb = A.base.pts[2 * c][3];
+            const float dd = dot(d, d), rdd = dd > 0.0f ? 1.0f / dd : 0.0f, rb = sc.base_pts[2 * c].w;
 #pragma unroll
             for (int ga = 0; ga < NGRP; ga++) {
                 V3 rel = xyz(gme[ga]) - e0;
@@ -444,8 +446,8 @@ LG_DEV void self_detect(const KArgs &A, const float *lds_tab, int ln, int m, Sel
                             va0 = xyz(sc.vel[ip0][ln]); va1 = xyz(sc.vel[ip1][ln]); vb0 = v0 + cross(w0, e0); vb1 = v0 + cross(w0, e1);
                         };
                         mB = A.base.mass_robot;
-                        if (cand & bit) hit = sa ? capsule_contact<true, false>(P, kn, xyz(pa0), xyz(pa1), pa0.w, e0, e1, A.base.pts[2 * j][3], vel, h)
-                                                 : capsule_contact<false, false>(P, kn, xyz(pa0), xyz(pa1), pa0.w, e0, e1, A.base.pts[2 * j][3], vel, h);
+                        if (cand & bit) hit = sa ? capsule_contact<true, false>(P, kn, xyz(pa0), xyz(pa1), pa0.w, e0, e1, sc.base_pts[2 * j].w, vel, h)
+                                                 : capsule_contact<false, false>(P, kn, xyz(pa0), xyz(pa1), pa0.w, e0, e1, sc.base_pts[2 * j].w, vel, h);
                     } else {
                         const int jp0 = T::cap_p0(j), jp1 = T::cap_p1(j);
                         const float4 pb0 = sc.pos[jp0][lp], pb1 = sc.pos[jp1][lp];
@@ -541,17 +543,20 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, int lane_k, float 
     HfFetch fb, fl[NPT];               // ground samples of all collision points: fetched here, evaluated after the loop
     V3 sgc[T::NGRP];          // self-collision: bounding-sphere centre of each point group (midpoint of its two anchor points)
     {
-        float sc = base_mass / A.base.mass, Il[6];
+        float mass_scale = base_mass / A.base.mass, Il[6];
 #pragma unroll
-        for (int i = 0; i < 6; i++) Il[i] = A.base.inertia[i] * sc;
+        for (int i = 0; i < 6; i++) Il[i] = A.base.inertia[i] * mass_scale;
         body_terms(grav, base_mass, v3(A.base.com[0], A.base.com[1], A.base.com[2]), Il, R0, w0, v0, I0b, p0b);
         // base collision points are split over the env's lanes (lane i owns point i); their inertia / bias contribution
         // joins the lane's limb contribution before the butterfly, their force is butterfly-summed afterwards
         static_assert(K <= LG_MAX_BASE_POINTS, "one base point per lane at most");
         {
             float bp[4] = {A.base.pts[0][0], A.base.pts[0][1], A.base.pts[0][2], A.base.pts[0][3]};
+            if constexpr (SC) { const float4 w = sc->base_pts[lane_k]; bp[0] = w.x; bp[1] = w.y; bp[2] = w.z; bp[3] = w.w; }     // staged copy (see SelfLds)
+            else {
 #pragma unroll
-            for (int i = 1; i < K; i++) if (lane_k == i) { bp[0] = A.base.pts[i][0]; bp[1] = A.base.pts[i][1]; bp[2] = A.base.pts[i][2]; bp[3] = A.base.pts[i][3]; }
+                for (int i = 1; i < K; i++) if (lane_k == i) { bp[0] = A.base.pts[i][0]; bp[1] = A.base.pts[i][1]; bp[2] = A.base.pts[i][2]; bp[3] = A.base.pts[i][3]; }
+            }
             cb.r = mul(R0, v3(bp[0], bp[1], bp[2]));
             cb.vc = v0 + cross(w0, cb.r);
             cb.depth = bp[3];                                            // radius until the ground height arrives
@@ -911,24 +916,39 @@ template <class T, int NW = LG_STEP_WAVES> struct HeightCrew {
     }
 };
 
-// The uniforms of a reset (Philox blocks keyed by env / step / purpose: ~0.27 us each on a lone wave) do not depend on the
-// state: in the multi-wave kernels the last helper wave draws them for EVERY lane while it waits for the first sub-step
-// (ResetRand::draw), and the rigid-body wave only reads the ones it needs -- a workgroup with a reset env no longer runs
-// 1.4 us behind the others (the kernel ends with its slowest workgroup).
+// The uniforms of a step (Philox blocks keyed by env / step / purpose: ~0.27 us each on a lone wave) do not depend on the
+// state: in the multi-wave kernels the helper waves draw them for EVERY lane during the first sub-step, when they have
+// delivered their torques / body terms and would otherwise wait (ResetRand::draw, slots dealt round-robin to the helpers), and
+// the rigid-body wave only reads the ones it needs: the observation noise (3 groups; the action group's scale is 0), the
+// command resampling, the push, and a reset's dof / root / command / terrain draws -- a workgroup with a reset env no longer
+// runs 1.4 us behind the others (the kernel ends with its slowest workgroup), and every workgroup saves ~1 us of noise draws.
 template <class T> struct ResetRand {
     static constexpr int NB = (T::L + 2) / 4 + 1;                  // Philox blocks covering the limb's L consecutive dofs
-    enum { ROOT0 = NB, ROOT1, CMD, TERRAIN, SLOTS };
+    static constexpr int NZB = T::L > 4 ? 2 : 1;                   // blocks per observation group of the lane
+    enum { ROOT0 = NB, ROOT1, CMD, TERRAIN, CMD_STEP, PUSH, NOISE, SLOTS = NOISE + 3 * NZB };
     float4 u[SLOTS][LG_BLOCK];
-    LG_DEV void draw(const lg_params &P, int e, int k, int64_t step, int lane) {
+    LG_DEV void put(const lg_params &P, int e, int64_t step, int lane, int slot, int purpose, int block) {
         float r[4];
+        rand4(P.seed, e, step, purpose, block, r);
+        u[slot][lane] = make_float4(r[0], r[1], r[2], r[3]);
+    }
+    // helper `h` of `nh` draws the slots s with s % nh == h (wave-uniform branches)
+    LG_DEV void draw(const lg_params &P, int e, int k, int64_t step, int lane, int h, int nh) {
         const int b0 = (k * T::L) >> 2;
 #pragma unroll
-        for (int i = 0; i < NB; i++) { rand4(P.seed, e, step, RNG_DOF, b0 + i, r); u[i][lane] = make_float4(r[0], r[1], r[2], r[3]); }
-        rand4(P.seed, e, step, RNG_ROOT, 0, r); u[ROOT0][lane] = make_float4(r[0], r[1], r[2], r[3]);
-        rand4(P.seed, e, step, RNG_ROOT, 1, r); u[ROOT1][lane] = make_float4(r[0], r[1], r[2], r[3]);
-        rand4(P.seed, e, step, RNG_CMD_RESET, 0, r); u[CMD][lane] = make_float4(r[0], r[1], r[2], r[3]);
-        if (P.terrain_curriculum) { rand4(P.seed, e, step, RNG_TERRAIN, 0, r); u[TERRAIN][lane] = make_float4(r[0], r[1], r[2], r[3]); }
+        for (int s = 0; s < SLOTS; s++) {
+            if (s % nh != h) continue;
+            if (s < NB) put(P, e, step, lane, s, RNG_DOF, b0 + s);
+            else if (s == ROOT0) put(P, e, step, lane, s, RNG_ROOT, 0);
+            else if (s == ROOT1) put(P, e, step, lane, s, RNG_ROOT, 1);
+            else if (s == CMD) put(P, e, step, lane, s, RNG_CMD_RESET, 0);
+            else if (s == TERRAIN) { if (P.terrain_curriculum) put(P, e, step, lane, s, RNG_TERRAIN, 0); }
+            else if (s == CMD_STEP) put(P, e, step, lane, s, RNG_CMD_STEP, 0);
+            else if (s == PUSH) { if (P.push_interval > 0 && step % P.push_interval == 0) put(P, e, step, lane, s, RNG_PUSH, 0); }
+            else if (P.add_noise) put(P, e, step, lane, s, RNG_NOISE, ((s - NOISE) / NZB * T::K + k) * 2 + (s - NOISE) % NZB);
+        }
     }
+    LG_DEV void get(int slot, int lane, float (&out)[4]) const { const float4 w = u[slot][lane]; out[0] = w.x; out[1] = w.y; out[2] = w.z; out[3] = w.w; }
 };
 
 // New state of a reset environment (reset_idx :147-191).  Every lane of the env computes the shared part
@@ -941,7 +961,7 @@ LG_DEV void reset_values(const KArgs &A, const float *tab, int e, int k, int64_t
     const lg_params &P = A.P;
     float u[4], v[4];
     auto uniforms = [&](int purpose, int block, int slot, float (&out)[4]) {
-        if (rr) { const float4 w = rr->u[slot][lane]; out[0] = w.x; out[1] = w.y; out[2] = w.z; out[3] = w.w; }
+        if (rr) rr->get(slot, lane, out);
         else rand4(P.seed, e, step, purpose, block, out);
     };
     level_changed = false;
@@ -989,7 +1009,8 @@ LG_DEV void reset_values(const KArgs &A, const float *tab, int e, int k, int64_t
 template <class T>
 LG_DEV void write_observations(const KArgs &A, int e, int k, bool live, int64_t step, const float *root, const float (&q)[T::L],
                                const float (&qd)[T::L], const float (&act)[T::L], const float *tab, V3 blv, V3 bav, V3 pg,
-                               const float (&cmd)[4], bool heights_from_buffer /* k_obs: also the height block, from measured_heights */) {
+                               const float (&cmd)[4], bool heights_from_buffer /* k_obs: also the height block, from measured_heights */,
+                               const ResetRand<T> *rr = nullptr, int lane = 0) {
     constexpr int K = T::K, L = T::L;
     const lg_params &P = A.P;
     float head[12] = {blv.x * P.obs_scale_lin_vel, blv.y * P.obs_scale_lin_vel, blv.z * P.obs_scale_lin_vel,
@@ -1013,14 +1034,18 @@ LG_DEV void write_observations(const KArgs &A, int e, int k, bool live, int64_t 
 #pragma unroll
     for (int g = 0; g < 4; g++) {
         float u[4], u2[4];
-        if (P.add_noise) {
-            rand4(P.seed, e, step, RNG_NOISE, (g * K + k) * 2, u);
-            if (L > 4) rand4(P.seed, e, step, RNG_NOISE, (g * K + k) * 2 + 1, u2);
+        const bool noisy = P.add_noise && g < 3;                   // the action group's noise scale is 0 (:230): no draw, same value
+        if (noisy) {
+            if (rr) { rr->get(ResetRand<T>::NOISE + g * ResetRand<T>::NZB, lane, u); if (L > 4) rr->get(ResetRand<T>::NOISE + g * ResetRand<T>::NZB + 1, lane, u2); }
+            else {
+                rand4(P.seed, e, step, RNG_NOISE, (g * K + k) * 2, u);
+                if (L > 4) rand4(P.seed, e, step, RNG_NOISE, (g * K + k) * 2 + 1, u2);
+            }
         }
 #pragma unroll
         for (int j = 0; j < L; j++) {
             float o = val[g][j];
-            if (P.add_noise) {
+            if (noisy) {
                 float uj = (j < 4) ? u[j & 3] : u2[j & 3];
                 o += (2.0f * uj - 1.0f) * nz[g][j];
             }
@@ -1052,6 +1077,12 @@ LG_DEV void write_observations(const KArgs &A, int e, int k, bool live, int64_t 
 }
 
 // ------------------------------------------------------------------ LDS staging helpers
+template <class T> LG_DEV void stage_base_points(const KArgs &A, SelfLds<T> *sc) {       // before stage_limb_table's barrier; static indices only
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < LG_MAX_BASE_POINTS; i++) sc->base_pts[i] = make_float4(A.base.pts[i][0], A.base.pts[i][1], A.base.pts[i][2], A.base.pts[i][3]);
+    }
+}
 template <class T> LG_DEV void stage_limb_table(const KArgs &A, float *lds_tab) {
     for (int i = threadIdx.x; i < T::K * Tab<T>::STRIDE; i += blockDim.x) lds_tab[i] = A.limb_table[i];
     __syncthreads();
@@ -1153,7 +1184,9 @@ struct EpisodeSums {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (lane < LG_NUM_REWARD_TERMS) {
-            const int slot = P.reward_slot[lane];
+            int slot = -1;                                         // P.reward_slot[lane] without a lane-dependent index into the kernarg struct
+#pragma unroll                                                     // (that makes hipcc copy all of KArgs to scratch)
+            for (int t = 0; t < LG_NUM_REWARD_TERMS; t++) slot = lane == t ? P.reward_slot[t] : slot;
             float tot = 0.0f;
             for (int i = 0; i < LG_BLOCK; i += K) tot += sh.r_t[lane][i];
             if (slot >= 0) atomicAdd(A.B.extras_accum + slot, tot);
@@ -1187,7 +1220,9 @@ template <class T, bool NET, bool HF, int NW, bool SC = false> struct HelperWave
                 lstm_split(u, part[a][0], part[a][1]);
             }
         }
-        if (wave == NW - 1) reset_rand->draw(P, e, k, step, lane);      // in the shadow of the rigid-body wave's prologue; published by the barriers below
+        // this wave's share of the step's uniforms, in the shadow of the rigid-body wave's prologue (kept out of the sub-step loop: its
+        // code would sit in the instruction cache next to the loop's); published by the barriers below
+        reset_rand->draw(P, e, k, step, lane, wave - 1, NW - 1);
         if (NET || OFF) {
             for (int it = 0; it < P.decimation; it++) {
                 __syncthreads();                                   // this sub-step has started: actuator inputs are in lds_x
@@ -1225,6 +1260,21 @@ template <class T, bool NET, bool HF, int NW, bool SC = false> struct HelperWave
                 }
             }
         }
+        if (NET) {
+            // The actuator state is final after the last sub-step's evaluation: written back HERE, while the rigid-body wave is still in
+            // that sub-step's passes, instead of after P3 where the conversion + eight stores per lane were the tail of every workgroup
+            // (the rigid-body wave waited ~1 us at the last barrier).  Stores of one lane to one address stay in order, so the zeroing of
+            // reset envs after P3 lands on top.
+#pragma unroll
+            for (int a = 0; a < 4; a++) {                          // unit-split -> per-row 8-vectors
+                float u[8];
+                lstm_unsplit(part[a][0], part[a][1], u);           // exchanges between lanes: every lane takes part, only live ones store
+                if (live) {
+                    reinterpret_cast<float4 *>(row[a])[0] = make_float4(u[0], u[1], u[2], u[3]);
+                    reinterpret_cast<float4 *>(row[a])[1] = make_float4(u[4], u[5], u[6], u[7]);
+                }
+            }
+        }
         __syncthreads();                                           // P1: final poses published
         HeightCrew<T, NW> hc;
         float hs = 0.0f;
@@ -1237,19 +1287,13 @@ template <class T, bool NET, bool HF, int NW, bool SC = false> struct HelperWave
         __syncthreads();                                           // P3: reset flags / post-reset root z / reward terms published
         if (wave == 1) es.template update<T::K>(A, e, lane, sh, keeper);
         if (P.measure_heights) hc.write_obs(A, e, k + T::K * wave, live, step, sh.root_z[lane]);
-        if (NET) {
-            const bool reset = sh.rst[lane] != 0;
+        if (NET) {                                                 // reset envs: actuator state zeroed (anymal.py:59-60), over the early write-back above
+            const bool reset = sh.rst[lane] != 0 && live;
+            if (__ballot(reset) != 0 && reset) {
 #pragma unroll
-            for (int a = 0; a < 4; a++) {                          // unit-split -> per-row 8-vectors, zeroed for reset envs (anymal.py:59-60)
-                float u[8];
-                lstm_unsplit(part[a][0], part[a][1], u);
-                if (reset) {
-#pragma unroll
-                    for (int i = 0; i < 8; i++) u[i] = 0.0f;
-                }
-                if (live) {
-                    reinterpret_cast<float4 *>(row[a])[0] = make_float4(u[0], u[1], u[2], u[3]);
-                    reinterpret_cast<float4 *>(row[a])[1] = make_float4(u[4], u[5], u[6], u[7]);
+                for (int a = 0; a < 4; a++) {
+                    reinterpret_cast<float4 *>(row[a])[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    reinterpret_cast<float4 *>(row[a])[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 }
             }
         }
@@ -1284,7 +1328,10 @@ __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
     __shared__ float lds_act[POL ? 16 : 1][16];                 // sampled actions [action][env in block]
     LG_PROF_BEGIN();
     if (threadIdx.x == 0) sh.fk_ready = 0;                      // published before the first use by stage_limb_table's barrier
-    if constexpr (SC) { if (threadIdx.x < LG_STEP_WAVES) sc_store.get()->ready[threadIdx.x] = 0; }
+    if constexpr (SC) {
+        if (threadIdx.x < LG_STEP_WAVES) sc_store.get()->ready[threadIdx.x] = 0;
+        stage_base_points<T>(A, sc_store.get());
+    }
     stage_limb_table<T>(A, lds_tab);
 
     const int N = P.num_envs;
@@ -1370,7 +1417,10 @@ __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
 #pragma unroll
     for (int i = 0; i < 4; i++) cmd[i] = B.commands[(size_t)e * 4 + i];
     // _post_physics_step_callback :329-345
-    if (ep_len % P.resample_interval == 0) resample_commands(P, e, step, RNG_CMD_STEP, cmd);
+    if (ep_len % P.resample_interval == 0) {
+        if (NW > 1 && P.decimation > 0) { float u[4]; reset_rand.get(ResetRand<T>::CMD_STEP, lane, u); resample_commands_u(P, u, cmd); }   // (decimation 0, parity tests: no barrier yet between the draw and here)
+        else resample_commands(P, e, step, RNG_CMD_STEP, cmd);
+    }
     if (P.heading_command) {
         V3 fwd = quat_apply(root + 3, v3(1, 0, 0));
         float heading = atan2f(fwd.y, fwd.x);
@@ -1388,7 +1438,8 @@ __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
     else if (NW == 2) hsum = sh.hsum[0][lane] + sh.hsum[1][lane];
     if (P.push_interval > 0 && step % P.push_interval == 0) {                     // _push_robots :438-444
         float u[4];
-        rand4(P.seed, e, step, RNG_PUSH, 0, u);
+        if (NW > 1) reset_rand.get(ResetRand<T>::PUSH, lane, u);
+        else rand4(P.seed, e, step, RNG_PUSH, 0, u);
         root[7] = urange(-P.max_push_vel, P.max_push_vel, u[0]);
         root[8] = urange(-P.max_push_vel, P.max_push_vel, u[1]);
     }
@@ -1522,7 +1573,7 @@ __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
     { int nr = 0; for (int i = 0; i < LG_BLOCK; i += K) nr += sh.rst[i]; LG_PROF_NOTE(18, (unsigned long long)nr); }
 #endif
     // compute_observations :130 (stale base-frame quantities for reset envs, as in the reference)
-    write_observations<T>(A, e, k, live, step, root, q, qd, act, tab, blv, bav, pg, cmd, false);
+    write_observations<T>(A, e, k, live, step, root, q, qd, act, tab, blv, bav, pg, cmd, false, NW > 1 ? &reset_rand : nullptr, lane);
     if (P.measure_heights) hc.write_obs(A, e, k, live, step, root[2]);
 
     LG_PROF(PF_POST_OBS);
@@ -1559,7 +1610,9 @@ __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
     // agent-scope release fence per workgroup measured +6 us); the ticket is taken after this wave's own memory operations
     // have drained (s_waitcnt vmcnt(0)), and the finisher reads with device-scope (L1-bypassing) loads.
     }   // physics wave
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // what the finisher reads: the episode atomics (helper wave 1; this wave if there is none) and terrain_levels (this wave's atomic
+    // stores, curriculum only) -- only those waves drain their memory operations before the ticket; plain state stores need not
+    if (NW == 1 || wave == 1 || (wave == 0 && P.terrain_curriculum)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     LG_PROF(PF_POST);
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1678,6 +1731,7 @@ __global__ void __launch_bounds__(LG_BLOCK) k_physics(const KArgs A, const float
     const lg_buffers &B = A.B;
     __shared__ float lds_tab[T::K * Tab<T>::STRIDE];
     __shared__ SelfStore<SC, T> sc_store;
+    if constexpr (SC) stage_base_points<T>(A, sc_store.get());
     stage_limb_table<T>(A, lds_tab);
     const int N = A.P.num_envs;
     const int tid = blockIdx.x * LG_BLOCK + threadIdx.x;
