@@ -1220,9 +1220,6 @@ template <class T, bool NET, bool HF, int NW, bool SC = false> struct HelperWave
                 lstm_split(u, part[a][0], part[a][1]);
             }
         }
-        // this wave's share of the step's uniforms, in the shadow of the rigid-body wave's prologue (kept out of the sub-step loop: its
-        // code would sit in the instruction cache next to the loop's); published by the barriers below
-        reset_rand->draw(P, e, k, step, lane, wave - 1, NW - 1);
         if (NET || OFF) {
             for (int it = 0; it < P.decimation; it++) {
                 __syncthreads();                                   // this sub-step has started: actuator inputs are in lds_x
@@ -1260,6 +1257,10 @@ template <class T, bool NET, bool HF, int NW, bool SC = false> struct HelperWave
                 }
             }
         }
+        // this wave's share of the step's uniforms: after its last hand-over, while the rigid-body wave is still in the last sub-step's
+        // passes (kept out of the sub-step loop -- its code would sit in the instruction cache next to the loop's -- and out of the
+        // prologue, where it delayed the first torques); published by P1, every reader is behind P1
+        reset_rand->draw(P, e, k, step, lane, wave - 1, NW - 1);
         if (NET) {
             // The actuator state is final after the last sub-step's evaluation: written back HERE, while the rigid-body wave is still in
             // that sub-step's passes, instead of after P3 where the conversion + eight stores per lane were the tail of every workgroup
@@ -1416,9 +1417,12 @@ __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
     float cmd[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) cmd[i] = B.commands[(size_t)e * 4 + i];
+    // _get_heights :831-869, by all four waves (HeightCrew); this wave is virtual lane k of its env
+    sh.pose[lane][0] = root[0]; sh.pose[lane][1] = root[1]; sh.pose[lane][2] = root[2]; sh.pose[lane][3] = root[5]; sh.pose[lane][4] = root[6];
+    __syncthreads();                                               // P1 (also publishes the helpers' uniforms)
     // _post_physics_step_callback :329-345
     if (ep_len % P.resample_interval == 0) {
-        if (NW > 1 && P.decimation > 0) { float u[4]; reset_rand.get(ResetRand<T>::CMD_STEP, lane, u); resample_commands_u(P, u, cmd); }   // (decimation 0, parity tests: no barrier yet between the draw and here)
+        if (NW > 1) { float u[4]; reset_rand.get(ResetRand<T>::CMD_STEP, lane, u); resample_commands_u(P, u, cmd); }
         else resample_commands(P, e, step, RNG_CMD_STEP, cmd);
     }
     if (P.heading_command) {
@@ -1426,9 +1430,6 @@ __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
         float heading = atan2f(fwd.y, fwd.x);
         cmd[2] = fminf(fmaxf(0.5f * wrap_to_pi(cmd[3] - heading), -1.0f), 1.0f);
     }
-    // _get_heights :831-869, by all four waves (HeightCrew); this wave is virtual lane k of its env
-    sh.pose[lane][0] = root[0]; sh.pose[lane][1] = root[1]; sh.pose[lane][2] = root[2]; sh.pose[lane][3] = root[5]; sh.pose[lane][4] = root[6];
-    __syncthreads();                                               // P1
     HeightCrew<T, NW> hc;
     float hsum = 0.0f;
     if (P.measure_heights) hsum = hc.template sample<HF>(A, e, k, live, root[0], root[1], root[2], root[5], root[6]);
