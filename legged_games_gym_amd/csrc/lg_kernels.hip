@@ -1200,7 +1200,7 @@ template <class T, bool NET, bool HF, int NW, bool SC = false> struct HelperWave
                                                                  // wave w takes bodies w-1, w-1 + (NW-1), ...
     static LG_DEV void run(const KArgs &A, int wave, int lane, int e, int k, int d0, bool live, int64_t step, const float *tab,
                            float2 (*lds_x)[LG_BLOCK], float (*lds_tau)[LG_BLOCK], StepSharedT<OFF, T::L> &sh, SelfLds<T> *sc = nullptr,
-                           const float *lds_tab = nullptr, ResetRand<T> *reset_rand = nullptr) {
+                           const float *lds_tab = nullptr, ResetRand<T> *reset_rand = nullptr, int *s_last = nullptr) {
         const lg_buffers &B = A.B;
         const lg_params &P = A.P;
         const int j = wave - 1;
@@ -1286,7 +1286,20 @@ template <class T, bool NET, bool HF, int NW, bool SC = false> struct HelperWave
         EpisodeSums es;
         if (keeper) es.load(A, e);
         __syncthreads();                                           // P3: reset flags / post-reset root z / reward terms published
-        if (wave == 1) es.template update<T::K>(A, e, lane, sh, keeper);
+        if (wave == 1) {
+            es.template update<T::K>(A, e, lane, sh, keeper);
+            // Workgroup ticket for the extras finisher, taken HERE: what the last workgroup's finisher reads are the episode-sum
+            // atomics just issued by this wave (and terrain levels, drained by the rigid-body wave before P3), so the ticket only
+            // has to follow their completion -- both round trips (drain, ticket) overlap the rigid-body wave's observations and
+            // state write-back instead of standing at the end of the kernel.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) {
+                const unsigned int ticket = atomicAdd(A.done_counter, 1u);
+                const int last = ticket == gridDim.x - 1;
+                if (last) __hip_atomic_store(A.done_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // idle until the next launch
+                *s_last = last;
+            }
+        }
         if (P.measure_heights) hc.write_obs(A, e, k + T::K * wave, live, step, sh.root_z[lane]);
         if (NET) {                                                 // reset envs: actuator state zeroed (anymal.py:59-60), over the early write-back above
             const bool reset = sh.rst[lane] != 0 && live;
@@ -1351,7 +1364,7 @@ __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
         __syncthreads();
     }
     if (wave > 0) {
-        HelperWave<T, NET, HF, NW, SC>::run(A, wave, lane, e, k, d0, live, step, tab, lds_x, lds_tau, sh, sc_store.get(), lds_tab, &reset_rand);
+        HelperWave<T, NET, HF, NW, SC>::run(A, wave, lane, e, k, d0, live, step, tab, lds_x, lds_tau, sh, sc_store.get(), lds_tab, &reset_rand, &s_last);
     } else {
     // ---- load persistent state (read once per env-step)
     float root[13], q[L], qd[L], act[L], tau[L];
@@ -1566,6 +1579,7 @@ __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
     }
 
     sh.rst[lane] = reset ? 1 : 0; sh.root_z[lane] = root[2];
+    if (NW > 1 && P.terrain_curriculum) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // terrain_levels stores precede the ticket (helper wave 1, after P3)
     __syncthreads();                                               // P3: helpers write the height observations / actuator state
     if (NW == 1) { EpisodeSums es; const bool keep = live && k == 0; if (keep) es.load(A, e); es.template update<K>(A, e, lane, sh, keep); }   // no helper wave: keep the sums here
 
@@ -1611,17 +1625,16 @@ __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
     // agent-scope release fence per workgroup measured +6 us); the ticket is taken after this wave's own memory operations
     // have drained (s_waitcnt vmcnt(0)), and the finisher reads with device-scope (L1-bypassing) loads.
     }   // physics wave
-    // what the finisher reads: the episode atomics (helper wave 1; this wave if there is none) and terrain_levels (this wave's atomic
-    // stores, curriculum only) -- only those waves drain their memory operations before the ticket; plain state stores need not
-    if (NW == 1 || wave == 1 || (wave == 0 && P.terrain_curriculum)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     LG_PROF(PF_POST);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned int ticket = atomicAdd(A.done_counter, 1u);
-        s_last = (ticket == gridDim.x - 1);
-        if (s_last) __hip_atomic_store(A.done_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // idle until the next launch
+    if (NW == 1) {                                                 // no helper wave: ticket at the end, behind this wave's own memory operations
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0) {
+            unsigned int ticket = atomicAdd(A.done_counter, 1u);
+            s_last = (ticket == gridDim.x - 1);
+            if (s_last) __hip_atomic_store(A.done_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // idle until the next launch
+        }
     }
-    __syncthreads();
+    __syncthreads();                                               // s_last published (NW > 1: helper wave 1 took the ticket after P3)
     if (s_last) finish_extras(A, threadIdx.x, step, true);
     LG_PROF_END(PF_EXTRAS, A.prof);
 }
