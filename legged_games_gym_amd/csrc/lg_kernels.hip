@@ -869,7 +869,9 @@ template <class T, int NW = LG_STEP_WAVES> struct HeightCrew {
                     int ix = (int)(px / P.hf_horizontal_scale), iy = (int)(py / P.hf_horizontal_scale);   // .long(): truncation
                     ix = min(max(ix, 0), P.hf_rows - 2); iy = min(max(iy, 0), P.hf_cols - 2);
                     const int16_t *hp = H + ix * P.hf_cols + iy;                   // rows x cols < 2^31 (checked at bind)
-                    s0[b][t] = hp[0]; s1[b][t] = hp[P.hf_cols]; s2[b][t] = hp[1];
+                    typedef int16_t pair16 __attribute__((ext_vector_type(2), aligned(2)));
+                    const pair16 w = *reinterpret_cast<const pair16 *>(hp);        // (ix, iy), (ix, iy + 1): neighbours in memory, one 4-byte gather
+                    s0[b][t] = w.x; s2[b][t] = w.y; s1[b][t] = hp[P.hf_cols];
                 }
         }
         float hsum = 0.0f;
@@ -890,7 +892,17 @@ template <class T, int NW = LG_STEP_WAVES> struct HeightCrew {
         return hsum;
     }
 
-    LG_DEV void write_obs(const KArgs &A, int e, int sub, bool live, int64_t step, float root_z) const {
+    // the height-noise uniforms of this thread's chunks (state-independent): drawn while the thread would otherwise wait
+    LG_DEV void draw_noise(const lg_params &P, int e, int sub, int64_t step, float (&un)[NCH][4]) const {
+        const int nchunk = (P.num_height_points + 3) >> 2;
+#pragma unroll
+        for (int b = 0; b < NCH; b++) {
+            const int c = sub + b * NV;
+            un[b][0] = un[b][1] = un[b][2] = un[b][3] = 0.0f;
+            if (c < nchunk && P.add_noise) rand4(P.seed, e, step, RNG_NOISE_H, c, un[b]);
+        }
+    }
+    LG_DEV void write_obs(const KArgs &A, int e, int sub, bool live, int64_t step, float root_z, const float (*un)[4] = nullptr) const {
         const lg_params &P = A.P;
         float *obs = A.B.obs_buf + (size_t)e * P.num_obs;
         const int np = P.num_height_points, nchunk = (np + 3) >> 2;
@@ -899,7 +911,10 @@ template <class T, int NW = LG_STEP_WAVES> struct HeightCrew {
             const int c = sub + b * NV;
             if (c < nchunk) {
                 float u[4] = {0, 0, 0, 0};
-                if (P.add_noise) rand4(P.seed, e, step, RNG_NOISE_H, c, u);
+                if (P.add_noise) {
+                    if (un) { u[0] = un[b][0]; u[1] = un[b][1]; u[2] = un[b][2]; u[3] = un[b][3]; }
+                    else rand4(P.seed, e, step, RNG_NOISE_H, c, u);
+                }
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
                     int i = 4 * c + t;
@@ -1103,15 +1118,16 @@ LG_DEV void finish_extras(const KArgs &A, int t, int64_t step_used, bool publish
         // each -- the serial 64-lane scan this replaces took 15 us at 4096 envs, and the kernel ends with this workgroup
         float acc = 0.0f;
         const int nt = blockDim.x;
-        for (int e0 = t; e0 < P.num_envs; e0 += nt * 8) {
-            int lv[8];
+        constexpr int INFLIGHT = 8;                                // (32 in flight measured no faster)
+        for (int e0 = t; e0 < P.num_envs; e0 += nt * INFLIGHT) {
+            int lv[INFLIGHT];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
+            for (int u = 0; u < INFLIGHT; u++) {
                 const int e = e0 + u * nt;
                 lv[u] = e < P.num_envs ? __hip_atomic_load(A.B.terrain_levels + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
             }
 #pragma unroll
-            for (int u = 0; u < 8; u++) acc += (float)lv[u];
+            for (int u = 0; u < INFLIGHT; u++) acc += (float)lv[u];
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
@@ -1200,7 +1216,7 @@ template <class T, bool NET, bool HF, int NW, bool SC = false> struct HelperWave
                                                                  // wave w takes bodies w-1, w-1 + (NW-1), ...
     static LG_DEV void run(const KArgs &A, int wave, int lane, int e, int k, int d0, bool live, int64_t step, const float *tab,
                            float2 (*lds_x)[LG_BLOCK], float (*lds_tau)[LG_BLOCK], StepSharedT<OFF, T::L> &sh, SelfLds<T> *sc = nullptr,
-                           const float *lds_tab = nullptr, ResetRand<T> *reset_rand = nullptr, int *s_last = nullptr) {
+                           const float *lds_tab = nullptr, ResetRand<T> *reset_rand = nullptr, int *s_last = nullptr, float4 (*hnoise)[LG_BLOCK] = nullptr) {
         const lg_buffers &B = A.B;
         const lg_params &P = A.P;
         const int j = wave - 1;
@@ -1261,6 +1277,18 @@ template <class T, bool NET, bool HF, int NW, bool SC = false> struct HelperWave
         // passes (kept out of the sub-step loop -- its code would sit in the instruction cache next to the loop's -- and out of the
         // prologue, where it delayed the first torques); published by P1, every reader is behind P1
         reset_rand->draw(P, e, k, step, lane, wave - 1, NW - 1);
+        if (P.measure_heights && P.add_noise) {                    // ... and the rigid-body wave's height-noise blocks (its chunks: sub = k)
+            const int nchunk = (P.num_height_points + 3) >> 2;
+#pragma unroll
+            for (int b = 0; b < HeightCrew<T, NW>::NCH; b++) {
+                const int c = k + b * HeightCrew<T, NW>::NV;
+                if (b % (NW > 1 ? NW - 1 : 1) == wave - 1 && c < nchunk) {
+                    float r[4];
+                    rand4(P.seed, e, step, RNG_NOISE_H, c, r);
+                    hnoise[b][lane] = make_float4(r[0], r[1], r[2], r[3]);
+                }
+            }
+        }
         if (NET) {
             // The actuator state is final after the last sub-step's evaluation: written back HERE, while the rigid-body wave is still in
             // that sub-step's passes, instead of after P3 where the conversion + eight stores per lane were the tail of every workgroup
@@ -1285,6 +1313,8 @@ template <class T, bool NET, bool HF, int NW, bool SC = false> struct HelperWave
         const bool keeper = wave == 1 && live && k == 0;           // one lane per env keeps the episode sums
         EpisodeSums es;
         if (keeper) es.load(A, e);
+        float un[HeightCrew<T, NW>::NCH][4];                       // this thread's height-noise uniforms, drawn while it waits for P3
+        if (P.measure_heights) hc.draw_noise(P, e, k + T::K * wave, step, un);
         __syncthreads();                                           // P3: reset flags / post-reset root z / reward terms published
         if (wave == 1) {
             es.template update<T::K>(A, e, lane, sh, keeper);
@@ -1300,7 +1330,7 @@ template <class T, bool NET, bool HF, int NW, bool SC = false> struct HelperWave
                 *s_last = last;
             }
         }
-        if (P.measure_heights) hc.write_obs(A, e, k + T::K * wave, live, step, sh.root_z[lane]);
+        if (P.measure_heights) hc.write_obs(A, e, k + T::K * wave, live, step, sh.root_z[lane], un);
         if (NET) {                                                 // reset envs: actuator state zeroed (anymal.py:59-60), over the early write-back above
             const bool reset = sh.rst[lane] != 0 && live;
             if (__ballot(reset) != 0 && reset) {
@@ -1336,7 +1366,8 @@ __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
     constexpr bool OFF = NW >= 2;
     __shared__ StepSharedT<OFF, L> sh;
     __shared__ SelfStore<SC, T> sc_store;
-    __shared__ ResetRand<T> reset_rand;                         // NW > 1: a reset's uniforms for every lane, drawn by the last helper wave
+    __shared__ ResetRand<T> reset_rand;                         // NW > 1: the step's state-independent uniforms for every lane, drawn by the helper waves
+    __shared__ float4 hnoise[NW > 1 ? HeightCrew<T, NW>::NCH : 1][LG_BLOCK];     // ... and this wave's height-noise blocks
     __shared__ int s_last;
     __shared__ float4 pol_xa[POL ? 4 : 1][64], pol_xb[POL ? 8 : 1][64], pol_xy[1][64];
     __shared__ float lds_act[POL ? 16 : 1][16];                 // sampled actions [action][env in block]
@@ -1364,7 +1395,7 @@ __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
         __syncthreads();
     }
     if (wave > 0) {
-        HelperWave<T, NET, HF, NW, SC>::run(A, wave, lane, e, k, d0, live, step, tab, lds_x, lds_tau, sh, sc_store.get(), lds_tab, &reset_rand, &s_last);
+        HelperWave<T, NET, HF, NW, SC>::run(A, wave, lane, e, k, d0, live, step, tab, lds_x, lds_tau, sh, sc_store.get(), lds_tab, &reset_rand, &s_last, hnoise);
     } else {
     // ---- load persistent state (read once per env-step)
     float root[13], q[L], qd[L], act[L], tau[L];
@@ -1589,7 +1620,14 @@ __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
 #endif
     // compute_observations :130 (stale base-frame quantities for reset envs, as in the reference)
     write_observations<T>(A, e, k, live, step, root, q, qd, act, tab, blv, bav, pg, cmd, false, NW > 1 ? &reset_rand : nullptr, lane);
-    if (P.measure_heights) hc.write_obs(A, e, k, live, step, root[2]);
+    if (P.measure_heights) {
+        if (NW > 1) {
+            float un[HeightCrew<T, NW>::NCH][4];
+#pragma unroll
+            for (int b = 0; b < HeightCrew<T, NW>::NCH; b++) { const float4 w = hnoise[b][lane]; un[b][0] = w.x; un[b][1] = w.y; un[b][2] = w.z; un[b][3] = w.w; }
+            hc.write_obs(A, e, k, live, step, root[2], un);
+        } else hc.write_obs(A, e, k, live, step, root[2]);
+    }
 
     LG_PROF(PF_POST_OBS);
     // ---- write persistent state back (written once per env-step)
