@@ -425,6 +425,7 @@ __global__ void __launch_bounds__(256) k_wide_reduce(const WideReduceArgs R) {
     const int n = i / ld, k = i % ld;
     if (k > K) return;
     float s = 0.0f;
+#pragma unroll 8                                   // same order of additions; eight independent loads in flight instead of one
     for (int p = 0; p < R.splits[z]; p++) s += R.part[z][(size_t)p * N * ld + i];
     if (k < K) R.gw[z][(size_t)n * K + k] = s;
     else R.gb[z][n] = s;

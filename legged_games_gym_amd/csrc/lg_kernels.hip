@@ -2210,7 +2210,7 @@ int lg_ppo_minibatch(const lg_mlp_net *nets, const int64_t *rows, int32_t mb, co
 }
 
 // ---- learner kernels for the wide MLPs (lg_gemm.h): per layer a tiled f32-MFMA GEMM with the element-wise work in its epilogue
-struct WideLayout { size_t x[4], g[4], part, x0p, w0p, total; int splits[4]; int kchunk[4]; int k0p; };      // float offsets into one net's workspace slice
+struct WideLayout { size_t x[4], g[4], part, x0p, w0p, wpk[4], bpk[4], total; int splits[4]; int kchunk[4]; int k0p; int ks[4], ot[4]; bool chain; };      // float offsets into one net's workspace slice
 static void wide_layout(const lg_mlp_net &n, int mb, WideLayout &L) {
     size_t o = 0;
     for (int l = 1; l <= 3; l++) { L.x[l] = o; o += (size_t)mb * n.dims[l]; }
@@ -2233,6 +2233,15 @@ static void wide_layout(const lg_mlp_net &n, int mb, WideLayout &L) {
     L.k0p = (n.dims[0] + 3) & ~3;                     // aligned, gather-free copies of the layer-0 operands (k_wide_prep)
     L.x0p = o; o += (size_t)mb * L.k0p;
     L.w0p = o; o += (size_t)n.dims[1] * L.k0p;
+    // chain forward (k_mlp_chain_fwd): split-bf16 operand streams of the four layers, re-packed every call
+    const int k0s = (n.dims[0] + 15) / 16;
+    L.chain = n.dims[1] == 512 && n.dims[2] == 256 && n.dims[3] == 128 && n.dims[4] <= 16 && (k0s == 15 || k0s == 11);
+    for (int l = 0; l < 4; l++) {
+        L.ks[l] = l == 0 ? k0s : n.dims[l] / 16; L.ot[l] = (n.dims[l + 1] + 31) / 32;
+        o = (o + 3) & ~(size_t)3;
+        L.wpk[l] = o; if (L.chain) o += (size_t)L.ot[l] * L.ks[l] * 512;          // 1024 bf16 per (tile, k-step)
+        L.bpk[l] = o; if (L.chain) o += (size_t)L.ot[l] * 32;
+    }
     L.total = (o + 3) & ~(size_t)3;
 }
 static int wide_check(const lg_mlp_net *nets, int32_t n_nets, int32_t mb) {
@@ -2282,6 +2291,45 @@ int lg_mlp_wide_forward(const lg_mlp_net *nets, int32_t n_nets, const int64_t *r
         pr.rows = rows; pr.mb = mb;
         int blocks = (int)((work + 255) / 256); if (blocks > 4096) blocks = 4096;
         hipLaunchKernelGGL(lg::k_wide_prep, dim3(blocks, n_nets), dim3(256), 0, st, pr);
+    }
+    bool chain = g_wide_precision == 1;
+    int k0s = 0;
+    for (int n = 0; n < n_nets; n++) {
+        WideLayout L; wide_layout(nets[n], mb, L);
+        chain = chain && L.chain && (n == 0 || L.ks[0] == k0s);
+        k0s = L.ks[0];
+    }
+    if (chain) {                                       // all four layers in one launch, activations on chip (lg_policy.h: k_mlp_chain_fwd)
+        lg::ChainPackArgs pk; memset(&pk, 0, sizeof pk);
+        lg::ChainArgs c; memset(&c, 0, sizeof c);
+        c.mb = mb;
+        float *ws = workspace;
+        size_t work = 0;
+        for (int n = 0; n < 2; n++) {
+            const int m = n < n_nets ? n : 0;          // a single net: the second descriptor mirrors the first (never launched: grid z / y = n_nets)
+            if (n == n_nets) ws = workspace;
+            WideLayout L; wide_layout(nets[m], mb, L);
+            lg::ChainNet &cn = c.net[n];
+            cn.x = ws + L.x0p; cn.ldx = L.k0p; cn.num_in = nets[m].dims[0];
+            for (int l = 0; l < 4; l++) {
+                pk.W[n][l] = nets[m].weights[l]; pk.b[n][l] = nets[m].biases[l];
+                pk.wp[n][l] = reinterpret_cast<__bf16 *>(ws + L.wpk[l]); pk.bp[n][l] = ws + L.bpk[l];
+                pk.in_dim[n][l] = nets[m].dims[l]; pk.out_dim[n][l] = nets[m].dims[l + 1]; pk.KS[n][l] = L.ks[l]; pk.OT[n][l] = L.ot[l];
+                cn.wb[l] = reinterpret_cast<const lg::bf16x8g *>(ws + L.wpk[l]); cn.bb[l] = ws + L.bpk[l];
+                const size_t w_ = (size_t)L.ot[l] * L.ks[l] * 512 + (size_t)L.ot[l] * 32;
+                if (w_ > work) work = w_;
+            }
+            for (int l = 0; l < 3; l++) { cn.act[l] = ws + L.x[l + 1]; cn.lda[l] = nets[m].dims[l + 1]; }
+            cn.out = nets[m].output; cn.out_dim = nets[m].dims[4];
+            ws += L.total;
+        }
+        int blocks = (int)((work + 255) / 256); if (blocks > 512) blocks = 512;
+        hipLaunchKernelGGL(lg::k_chain_pack, dim3(blocks, 4, n_nets), dim3(256), 0, st, pk);
+        const dim3 grid((mb + LG_PW_ENVS - 1) / LG_PW_ENVS, n_nets), block(64 * LG_PW_WAVES);
+        if (k0s == 15) hipLaunchKernelGGL((lg::k_mlp_chain_fwd<15, 16, 8, 4>), grid, block, 0, st, c);
+        else hipLaunchKernelGGL((lg::k_mlp_chain_fwd<11, 16, 8, 4>), grid, block, 0, st, c);
+        HIP_TRY(hipGetLastError());
+        return 0;
     }
     for (int l = 0; l < 4; l++) {
         lg::GemmArgs a; memset(&a, 0, sizeof a);

@@ -296,9 +296,106 @@ __global__ void __launch_bounds__(64 * LG_PW_WAVES) k_policy_act_wide(const Poli
     }
 }
 
+// ------------------------------------------------------------------ the same chain as the LEARNER's forward pass
+// lg_mlp_wide_forward at precision 1 for the 235/169-512-256-128 shapes: 32 mini-batch rows per workgroup walk all four layers with
+// the activations in LDS; what the backward pass needs (the post-ELU activations of the three hidden layers, f32, row-major) is
+// written out on the way -- 128 contiguous bytes per row and tile -- and nothing is read back.  The layer-by-layer GEMMs this
+// replaces moved every activation through HBM twice (forward: 226 us per mini-batch of 24 576 rows, both nets).
+struct ChainNet {
+    const float *x; int ldx, num_in;       // gathered, padded input rows (k_wide_prep's copy)
+    const bf16x8g *wb[4]; const float *bb[4];
+    float *act[3]; int lda[3];             // hidden activations, [mb][width]
+    float *out; int out_dim;               // [mb][out_dim]
+};
+struct ChainArgs { ChainNet net[2]; int mb; };
+
+template <int TPW>
+LG_DEV void chain_epilogue(const f32x16p (&acc)[TPW], const float *__restrict__ b, bf16x8g (*xout)[2][64], int o0, int lane,
+                           float *__restrict__ act_row /* this lane's row, or null */) {
+    const int h = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < TPW; t++) {
+        const float *bo = b + 32 * (o0 + t) + 4 * h;
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = elu1(acc[t][8 * jj + i] + bo[8 * (2 * jj + (i >> 2)) + (i & 3)]);
+            if (act_row) {
+                float *dst = act_row + 32 * (o0 + t) + 16 * jj + 4 * h;          // features 32o + 8(2jj + j') + 4h + r
+                *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4 *>(dst + 8) = make_float4(v[4], v[5], v[6], v[7]);
+            }
+            bf16x8g hi, lo;
+            split8(v, hi, lo);
+            xout[2 * (o0 + t) + jj][0][lane] = hi; xout[2 * (o0 + t) + jj][1][lane] = lo;
+        }
+    }
+}
+
+template <int K0S, int H1T, int H2T, int H3T>
+__global__ void __launch_bounds__(64 * LG_PW_WAVES) k_mlp_chain_fwd(const ChainArgs C) {
+    const ChainNet &N = C.net[blockIdx.y];
+    constexpr int NW = LG_PW_WAVES;
+    constexpr int T1 = H1T / NW, T2 = H2T >= NW ? H2T / NW : 1, T3 = 1;
+    constexpr int KA = K0S > 2 * H2T ? K0S : 2 * H2T, KB = H1T > H3T ? 2 * H1T : 2 * H3T;
+    __shared__ bf16x8g xa[KA][2][64], xb[KB][2][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5;
+    const int wv = (wave + blockIdx.x) % NW;
+    const int r0 = (blockIdx.x * 5) % K0S, r1 = (blockIdx.x * 5) % (2 * H1T), r2 = (blockIdx.x * 5) % (2 * H2T);
+    const bool on2 = wv * T2 < H2T, on3 = wv * T3 < H3T;
+    WideStream<K0S, T1> s1;
+    s1.prime(N.wb[0], wv * T1, r0, lane);
+    int row = blockIdx.x * LG_PW_ENVS + (lane & 31);
+    const bool live = row < C.mb;
+    if (!live) row = C.mb - 1;
+    const float *o = N.x + (size_t)row * N.ldx;
+    for (int s = wave; s < K0S; s += NW) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) { const int k = 16 * s + 8 * h + i; v[i] = k < N.num_in ? o[k] : 0.0f; }
+        bf16x8g hi, lo;
+        split8(v, hi, lo);
+        xa[s][0][lane] = hi; xa[s][1][lane] = lo;
+    }
+    __syncthreads();
+    f32x16p a1[T1];
+    s1.run(N.wb[0], xa, wv * T1, r0, lane, a1);
+    WideStream<2 * H1T, T2> s2;
+    if (on2) s2.prime(N.wb[1], wv * T2, r1, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    chain_epilogue<T1>(a1, N.bb[0], xb, wv * T1, lane, live ? N.act[0] + (size_t)row * N.lda[0] : nullptr);
+    __syncthreads();
+    f32x16p a2[T2];
+    WideStream<2 * H2T, T3> s3;
+    if (on2) s2.run(N.wb[1], xb, wv * T2, r1, lane, a2);
+    if (on3) s3.prime(N.wb[2], wv * T3, r2, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    if (on2) chain_epilogue<T2>(a2, N.bb[1], xa, wv * T2, lane, live ? N.act[1] + (size_t)row * N.lda[1] : nullptr);
+    __syncthreads();
+    f32x16p a3[T3];
+    WideStream<2 * H3T, 1> s4;
+    if (on3) s3.run(N.wb[2], xa, wv * T3, r2, lane, a3);
+    if (wave == 0) s4.prime(N.wb[3], 0, 0, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    if (on3) chain_epilogue<T3>(a3, N.bb[2], xb, wv * T3, lane, live ? N.act[2] + (size_t)row * N.lda[2] : nullptr);
+    __syncthreads();
+    if (wave != 0) return;
+    f32x16p y[1];
+    s4.run(N.wb[3], xb, 0, 0, lane, y);
+    if (!live) return;
+#pragma unroll
+    for (int ii = 0; ii < 2; ii++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int a = 8 * ii + 4 * h + r;                      // register i = 4ii + r of lane (row, h) is output 8ii + 4h + r
+            if (a < N.out_dim) N.out[(size_t)row * N.out_dim + a] = y[0][4 * ii + r] + N.bb[3][a];
+        }
+}
+
 // torch Linear [out, in] f32 -> the operand stream above; `first` selects the natural k order of layer 0
-__global__ void k_policy_pack_wide(const float *__restrict__ Wt, const float *__restrict__ bias, int in_dim, int out_dim, int KS, int OT, int first,
-                                   __bf16 *__restrict__ wp, float *__restrict__ bp) {
+LG_DEV void pack_wide_body(const float *__restrict__ Wt, const float *__restrict__ bias, int in_dim, int out_dim, int KS, int OT, int first,
+                           __bf16 *__restrict__ wp, float *__restrict__ bp) {
     const size_t n = (size_t)OT * KS * 64 * 8;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < n + (size_t)OT * 32; idx += (size_t)gridDim.x * blockDim.x) {
         if (idx >= n) { const int r = (int)(idx - n); bp[r] = r < out_dim ? bias[r] : 0.0f; continue; }
@@ -312,6 +409,16 @@ __global__ void k_policy_pack_wide(const float *__restrict__ Wt, const float *__
         wp[((((size_t)o * KS + s) * 2 + 0) * 64 + l) * 8 + i] = hi;
         wp[((((size_t)o * KS + s) * 2 + 1) * 64 + l) * 8 + i] = lo;
     }
+}
+__global__ void k_policy_pack_wide(const float *__restrict__ Wt, const float *__restrict__ bias, int in_dim, int out_dim, int KS, int OT, int first,
+                                   __bf16 *__restrict__ wp, float *__restrict__ bp) {
+    pack_wide_body(Wt, bias, in_dim, out_dim, KS, OT, first, wp, bp);
+}
+// all layers of up to two nets in one launch (the learner re-packs after every optimiser step): blockIdx.y = layer, blockIdx.z = net
+struct ChainPackArgs { const float *W[2][4], *b[2][4]; __bf16 *wp[2][4]; float *bp[2][4]; int in_dim[2][4], out_dim[2][4], KS[2][4], OT[2][4]; };
+__global__ void k_chain_pack(const ChainPackArgs P) {
+    const int l = blockIdx.y, z = blockIdx.z;
+    pack_wide_body(P.W[z][l], P.b[z][l], P.in_dim[z][l], P.out_dim[z][l], P.KS[z][l], P.OT[z][l], l == 0 ? 1 : 0, P.wp[z][l], P.bp[z][l]);
 }
 
 }  // namespace lg

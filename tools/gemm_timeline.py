@@ -1,5 +1,5 @@
 import csv,sys
-rows=[r for r in csv.DictReader(open(sys.argv[1])) if "k_gemm_wide" in r["Kernel_Name"] or "k_wide_" in r["Kernel_Name"]]
+rows=[r for r in csv.DictReader(open(sys.argv[1])) if any(t in r["Kernel_Name"] for t in ("k_gemm_wide", "k_wide_", "k_mlp_chain", "k_chain_pack"))]
 rows.sort(key=lambda r:int(r["Start_Timestamp"]))
 seq=rows[-16:]
 t0=int(seq[0]["Start_Timestamp"])
