@@ -103,14 +103,28 @@ def main():
 
 def workload_text(task, env, pol, num_envs):
     cfg = env.cfg
+    # what the kernel collides against is in the bound parameters (cfg.terrain.mesh_type is restored to the registered value after make_env)
+    thr = float(getattr(getattr(env, "_params", None), "hf_step_threshold", 0.0) or 0.0)
     terrain = "plane" if cfg.terrain.mesh_type in (None, "none", "plane") else \
-        f"{env.terrain.tot_rows}x{env.terrain.tot_cols} int16 curriculum height field ({cfg.terrain.mesh_type})"
+        (f"{env.terrain.tot_rows}x{env.terrain.tot_cols} int16 curriculum height field, " +
+         (f"'trimesh' contact: vertical faces beyond {thr:.3f} m per cell (slope_treshold)" if thr > 0.0 else
+          "height-field contact: bilinear patches (BASELINE.json configs 3-5; the registered 'trimesh' faces with --trimesh)"))
     ctrl = "actuator-net torques" if getattr(cfg.control, "use_actuator_network", False) else f"PD control ({cfg.control.control_type})"
     sc = "self-collision ON (asset.self_collisions = 0)" if getattr(env, "self_collision_modelled", False) else \
         ("self-collision requested by the config but NOT modelled" if int(getattr(cfg.asset, "self_collisions", 1)) == 0 else "self-collision off (as configured)")
     return (f"{task}, {num_envs} envs/GPU, {terrain}, {ctrl}, {sc}, random-init policy "
             f"{[env.num_obs] + list(pol['actor_hidden_dims']) + [env.num_actions]} rollout (act = mu + sigma*eps), "
             "fixed command (0.5,0,0), obs noise + friction/mass randomisation + pushes on")
+
+
+def _update_path(alg):
+    tr = getattr(alg, "_mlp", None)
+    if tr is None:
+        return "torch autograd"
+    if getattr(tr, "has_fused_minibatch", False):
+        return "lg_ppo_minibatch: forward + PPO loss + backward in one f32-MFMA kernel (v_mfma_f32_16x16x4_f32), lg_adam_step; one HIP graph per update"
+    return ("wide learner kernels: chain forward k_mlp_chain_fwd + tiled dX / dW GEMMs, split-bf16 products (hi*hi + hi*lo + lo*hi, f32 accumulate) "
+            "on v_mfma_f32_32x32x16_bf16 (lg_mlp_wide_set_precision(1), the default; 0 = f32 MFMA), lg_ppo_loss, lg_adam_step")
 
 
 def worker(a):
@@ -389,7 +403,7 @@ def training_leg(a, iters, rank, local_rank, world, coll_dev, ranks_seen, backen
     alg = runner.alg
     out = {"value": world * a.num_envs * T * iters / dt, "unit": "env-steps/s (rollout + PPO update, whole job)", "iterations": iters,
            "ms_per_iteration": 1e3 * dt / iters, "steps_per_env": T, "epochs_x_minibatches": [alg.num_learning_epochs, alg.num_mini_batches],
-           "update_path": getattr(alg, "update_path_name", lambda: "MFMA learner kernels" if getattr(alg, "_mlp", None) is not None else "torch autograd")(),
+           "update_path": _update_path(alg),
            "final_learning_rate": float(alg.learning_rate),
            "note": "includes re-capturing the rollout graph at the start of the timed learn() call"}
     if world > 1:

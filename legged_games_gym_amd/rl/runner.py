@@ -70,13 +70,17 @@ class OnPolicyRunner:
         return actions, mean, env.step(actions)
 
     def _critic_values(self, st):
-        """critic(obs) for all stored transitions: lg_mlp_forward when the critic has the learner kernels' shape, torch otherwise."""
+        """critic(obs) for all stored transitions: lg_mlp_forward / lg_mlp_wide_forward when the critic has one of the learner kernels' shapes, torch otherwise."""
         ac = self.alg.actor_critic
         cobs = (st.privileged_observations if st.privileged_observations is not None else st.observations).flatten(0, 1)
         tr = getattr(self, "_critic_fwd", None)
         if tr is None or (tr is not False and (tr.inputs[0].data_ptr() != cobs.data_ptr() or tr.mb != cobs.shape[0])):
-            from .mlp_kernels import MlpTrainer
-            tr = MlpTrainer([ac.critic], [cobs], cobs.shape[0], forward_only=True) if isinstance(ac.critic, torch.nn.Sequential) else False
+            from .mlp_kernels import MlpTrainer, WideMlpTrainer
+            tr = False
+            if isinstance(ac.critic, torch.nn.Sequential) and cobs.is_cuda:
+                tr = MlpTrainer([ac.critic], [cobs], cobs.shape[0], forward_only=True)
+                if not tr.supported:                  # the 512-256-128 critics: the chain forward of the wide learner kernels
+                    tr = WideMlpTrainer([ac.critic], [cobs], cobs.shape[0], forward_only=True)
             self._critic_fwd = tr
         if tr is not False and tr.supported:
             tr.refresh()                              # parameter addresses (stable; the values follow the optimiser)
