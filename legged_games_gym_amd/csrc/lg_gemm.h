@@ -116,11 +116,32 @@ LG_DEV void gemm_epilogue(const GemmNet &N, float *C, const f32x16g (&acc)[2][2]
 // A tile element is (r, k): r = index on the output-tile side (0..127), k = reduction index inside the stage (0..15).
 //   k-contiguous operand (A of FWD / DX, B of FWD):  thread t holds k = 4 (t & 3) .. +3 of rows r = (t >> 2) + 64 e,  e = 0, 1
 //   r-contiguous operand (B of DX, A and B of DW):   thread t holds r = 4 (t & 31) .. +3 of k = (t >> 5) + 8 e,      e = 0, 1
+// blockIdx -> (tile_m, tile_n, split), XCD-aware.  Workgroups are handed to the 8 XCDs round-robin by linear id, each XCD has its own
+// 4 MB L2, and the tiles that read the same operand rows -- the tiles_m x tiles_n tiles of one dW row-chunk, the tiles_n column tiles of one
+// row tile in FWD / DX -- were 4-192 ids apart: on different XCDs or at different times, so every re-read went to the Infinity Cache /
+// HBM (dW of layer 0: 386 MB of traffic for 146 MB of operands, 4.6 TB/s).  Here the ids of one residue class mod 8 (= one XCD, in
+// dispatch order) are mapped to CONSECUTIVE logical tiles, so the sharers run side by side on one L2 and walk their k-slabs in step.
+template <int MODE> LG_DEV bool tile_coords(const GemmNet &N, int &tile_m, int &tile_n, int &split) {
+    const int T = gridDim.x * gridDim.y, i = blockIdx.x + gridDim.x * blockIdx.y;
+    const int q = T >> 3, r = T & 7, c = i & 7, j = i >> 3;
+    const int L = (c < r ? c * (q + 1) : r * (q + 1) + (c - r) * q) + j;         // bijection [0, T) -> [0, T)
+    const int per = N.tiles_m * N.tiles_n;
+    if (MODE == GEMM_DW) {
+        split = L / per;
+        const int tile = L - split * per;
+        tile_m = tile % N.tiles_m; tile_n = tile / N.tiles_m;
+        return split < N.splits;
+    }
+    split = 0;
+    tile_m = L / N.tiles_n; tile_n = L - tile_m * N.tiles_n;
+    return tile_m < N.tiles_m;
+}
+
 template <int MODE>
 __global__ void __launch_bounds__(256) k_gemm_wide(const GemmArgs G) {
     const GemmNet &N = G.net[blockIdx.z];
-    const int tile_m = blockIdx.x, tile_n = blockIdx.y % N.tiles_n, split = MODE == GEMM_DW ? blockIdx.y / N.tiles_n : 0;
-    if (tile_m >= N.tiles_m || blockIdx.y >= N.tiles_n * (MODE == GEMM_DW ? N.splits : 1)) return;      // the grid is sized for the larger net
+    int tile_m, tile_n, split;
+    if (!tile_coords<MODE>(N, tile_m, tile_n, split)) return;                    // the grid is sized for the larger net
     __shared__ GemmStage st[2];
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63, wy = wave >> 1, wx = wave & 1;
     const int m0 = tile_m * LG_GT, n0 = tile_n * LG_GT;
@@ -266,8 +287,8 @@ LG_DEV void split4(float4 x, bf16x4g &hi, bf16x4g &lo) {
 template <int MODE>
 __global__ void __launch_bounds__(256) k_gemm_wide_bf16x3(const GemmArgs G) {
     const GemmNet &N = G.net[blockIdx.z];
-    const int tile_m = blockIdx.x, tile_n = blockIdx.y % N.tiles_n, split = MODE == GEMM_DW ? blockIdx.y / N.tiles_n : 0;
-    if (tile_m >= N.tiles_m || blockIdx.y >= N.tiles_n * (MODE == GEMM_DW ? N.splits : 1)) return;
+    int tile_m, tile_n, split;
+    if (!tile_coords<MODE>(N, tile_m, tile_n, split)) return;                    // the grid is sized for the larger net
     __shared__ GemmStageB st;
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63, wy = wave >> 1, wx = wave & 1;
     const int m0 = tile_m * LG_GT, n0 = tile_n * LG_GT;

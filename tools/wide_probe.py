@@ -15,10 +15,10 @@ actor, critic = mlp(obs, 12, 0), mlp(obs, 1, 1)
 x = torch.randn(98304, obs, device="cuda")
 rows = torch.randperm(98304, device="cuda")[:mb]
 tr = WideMlpTrainer([actor, critic], [x, x], mb)
-for _ in range(3):
+for _ in range(1 if os.environ.get("WIDE_ITERS") else 3):
     tr.forward(rows); tr.backward(rows)
 torch.cuda.synchronize(); t0 = time.perf_counter()
-n = 20
+n = int(os.environ.get("WIDE_ITERS", "20"))
 for _ in range(n):
     tr.forward(rows); tr.backward(rows)
 torch.cuda.synchronize()
