@@ -278,6 +278,23 @@ typedef __bf16 bf16x4g __attribute__((ext_vector_type(4)));
 typedef float f32x4g __attribute__((ext_vector_type(4)));
 struct GemmStageB { __bf16 ahi[LG_GT][LG_BLD], alo[LG_GT][LG_BLD], bhi[LG_GT][LG_BLD], blo[LG_GT][LG_BLD]; };      // 40 KB
 
+#define LG_TRS 160                     // bf16 per row of a [k][feature] image: 128 features + 32 pad = 320 bytes (= 64 mod 256: the four
+                                       // rows a transposed read gathers sit on disjoint bank groups); 32 x 320 B = the 10 240 B of a [128][40] image
+static_assert(LG_BK * LG_TRS == LG_GT * LG_BLD, "the two image layouts share one buffer");
+typedef short s16x4g __attribute__((ext_vector_type(4)));
+// MFMA 32x32x16 operand fragment of rows r0 .. r0+31, k = ks .. ks+15 from a [k][feature] image: lane l needs feature r0 + (l & 31),
+// k = ks + 8 (l >> 5) + 0..7.  ds_read_b64_tr_b16 (gfx950): every 16-lane group reads a 4 (k) x 16 (feature) block and lane i of the
+// group receives column i; lane 4q + p of the group supplies the address of row q, columns 4p .. 4p+3 (tools/ubench/tr16_probe.hip
+// checks this mapping on the device).  EXEC must be full: called from the uniform main loop only.
+LG_DEV bf16x8g frag_tr(const __bf16 *img, int r0, int ks, int lane) {
+    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const __bf16 *a = img + (ks + 8 * (g >> 1) + q) * LG_TRS + r0 + 16 * (g & 1) + 4 * p;
+    const s16x4g v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4g *)a);
+    const s16x4g v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4g *)(a + 4 * LG_TRS));
+    union { struct { s16x4g lo, hi; } s; bf16x8g v; } u;
+    u.s.lo = v0; u.s.hi = v1;
+    return u.v;
+}
 LG_DEV void split4(float4 x, bf16x4g &hi, bf16x4g &lo) {
     const f32x4g v = {x.x, x.y, x.z, x.w};
     hi = __builtin_convertvector(v, bf16x4g);
@@ -324,7 +341,27 @@ __global__ void __launch_bounds__(256) k_gemm_wide_bf16x3(const GemmArgs G) {
         for (int c = 0; c < 4; c++) brow_next[c] = G.rows[min(k_begin + 4 * (t >> 5) + c, max(k_end - 1, 0))];
     }
     float4 ra[4], rb[4];
+    // Fast path of a stage's loads: the whole k-slab is inside the range and every lane's four elements are either all valid or all
+    // outside the matrix (widths that are multiples of 4) -- one predicated 16-byte load per operand quad.  The general load4() with its
+    // per-element tails costs ~25 executed instructions per quad even when no tail exists: with it a stage was ~700 instructions per
+    // wave for 24 MFMAs and the kernels were instruction-issue bound.
+    const bool quads = (N.M & 3) == 0 && (N.N & 3) == 0 && !(MODE == GEMM_DW && G.gather_b_k) && !(MODE == GEMM_FWD && G.gather_a_rows);
+    auto ld4 = [&](const float *p, bool ok) {
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) { const f32x4u v = *reinterpret_cast<const f32x4u *>(p); r = make_float4(v.x, v.y, v.z, v.w); }
+        return r;
+    };
     auto load_stage = [&](int kb) {
+        if (quads && kb + LG_BK <= k_end) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                if (A_KC) ra[c] = ld4(pa + kb + 16 * (t & 1) + 4 * c, na != 0);
+                else ra[c] = ld4(pa + (size_t)(kb + 4 * (t >> 5) + c) * N.lda, na == 4);
+                if (B_KC) rb[c] = ld4(pb + kb + 16 * (t & 1) + 4 * c, nb != 0);
+                else rb[c] = ld4(pb + (size_t)(kb + 4 * (t >> 5) + c) * N.ldb, nb == 4);
+            }
+            return;
+        }
 #pragma unroll
         for (int c = 0; c < 4; c++) {
             if (A_KC) { const int k = kb + 16 * (t & 1) + 4 * c; ra[c] = load4(pa + k, na ? k_end - k : 0); }
@@ -351,19 +388,22 @@ __global__ void __launch_bounds__(256) k_gemm_wide_bf16x3(const GemmArgs G) {
                 *reinterpret_cast<bf16x8g *>(&lo[r][k + 8 * h]) = bf16x8g{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
             }
         };
-        auto put_rc = [&](__bf16 (*hi)[LG_BLD], __bf16 (*lo)[LG_BLD], const float4 (&v)[4]) {
+        // operand that is NOT k-contiguous in memory (dW: both; dX: the weights): image [k][feature], rows of LG_TRS bf16.  A thread's
+        // float4 (4 consecutive features of one k) is one 8-byte write and a half-wave's 32 writes are 256 contiguous bytes -- the
+        // earlier [feature][k] image put the lanes 4 rows = 320 B apart: 2 of 32 banks, every write 16-way conflicted (the GEMMs ran
+        // at a fifth of the matrix-core rate).  The MFMA fragments are read back transposed by ds_read_b64_tr_b16 (frag_tr).
+        auto put_rc = [&](__bf16 *hi, __bf16 *lo, const float4 (&v)[4]) {
             const int r = 4 * (t & 31), k = 4 * (t >> 5);
-            bf16x4g h[4], l[4];
 #pragma unroll
-            for (int c = 0; c < 4; c++) split4(v[c], h[c], l[c]);            // h[c][i]: k + c, row r + i
-#pragma unroll
-            for (int i = 0; i < 4; i++) {                                     // register transpose: 4 consecutive k of row r + i
-                *reinterpret_cast<bf16x4g *>(&hi[r + i][k]) = bf16x4g{h[0][i], h[1][i], h[2][i], h[3][i]};
-                *reinterpret_cast<bf16x4g *>(&lo[r + i][k]) = bf16x4g{l[0][i], l[1][i], l[2][i], l[3][i]};
+            for (int c = 0; c < 4; c++) {
+                bf16x4g h, l;
+                split4(v[c], h, l);
+                *reinterpret_cast<bf16x4g *>(hi + (k + c) * LG_TRS + r) = h;
+                *reinterpret_cast<bf16x4g *>(lo + (k + c) * LG_TRS + r) = l;
             }
         };
-        if (A_KC) put_kc(st.ahi, st.alo, ra); else put_rc(st.ahi, st.alo, ra);
-        if (B_KC) put_kc(st.bhi, st.blo, rb); else put_rc(st.bhi, st.blo, rb);
+        if (A_KC) put_kc(st.ahi, st.alo, ra); else put_rc(&st.ahi[0][0], &st.alo[0][0], ra);
+        if (B_KC) put_kc(st.bhi, st.blo, rb); else put_rc(&st.bhi[0][0], &st.blo[0][0], rb);
         if (MODE == GEMM_DW && tile_n == 0) {             // bias gradient: exact f32 column sums of the G tile this thread just staged
 #pragma unroll
             for (int c = 0; c < 4; c++) { cs4[0] += ra[c].x; cs4[1] += ra[c].y; cs4[2] += ra[c].z; cs4[3] += ra[c].w; }
@@ -388,10 +428,20 @@ __global__ void __launch_bounds__(256) k_gemm_wide_bf16x3(const GemmArgs G) {
             bf16x8g ah[2], al[2], bh[2], bl[2];
 #pragma unroll
             for (int i = 0; i < 2; i++) {
-                ah[i] = *reinterpret_cast<const bf16x8g *>(&st.ahi[64 * wy + 32 * i + li][ks + 8 * lh]);
-                al[i] = *reinterpret_cast<const bf16x8g *>(&st.alo[64 * wy + 32 * i + li][ks + 8 * lh]);
-                bh[i] = *reinterpret_cast<const bf16x8g *>(&st.bhi[64 * wx + 32 * i + li][ks + 8 * lh]);
-                bl[i] = *reinterpret_cast<const bf16x8g *>(&st.blo[64 * wx + 32 * i + li][ks + 8 * lh]);
+                if (A_KC) {
+                    ah[i] = *reinterpret_cast<const bf16x8g *>(&st.ahi[64 * wy + 32 * i + li][ks + 8 * lh]);
+                    al[i] = *reinterpret_cast<const bf16x8g *>(&st.alo[64 * wy + 32 * i + li][ks + 8 * lh]);
+                } else {
+                    ah[i] = frag_tr(&st.ahi[0][0], 64 * wy + 32 * i, ks, lane);
+                    al[i] = frag_tr(&st.alo[0][0], 64 * wy + 32 * i, ks, lane);
+                }
+                if (B_KC) {
+                    bh[i] = *reinterpret_cast<const bf16x8g *>(&st.bhi[64 * wx + 32 * i + li][ks + 8 * lh]);
+                    bl[i] = *reinterpret_cast<const bf16x8g *>(&st.blo[64 * wx + 32 * i + li][ks + 8 * lh]);
+                } else {
+                    bh[i] = frag_tr(&st.bhi[0][0], 64 * wx + 32 * i, ks, lane);
+                    bl[i] = frag_tr(&st.blo[0][0], 64 * wx + 32 * i, ks, lane);
+                }
             }
 #pragma unroll
             for (int i = 0; i < 2; i++)

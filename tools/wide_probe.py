@@ -10,7 +10,7 @@ def mlp(i, o, seed):
     torch.manual_seed(seed)
     return nn.Sequential(nn.Linear(i, 512), nn.ELU(), nn.Linear(512, 256), nn.ELU(), nn.Linear(256, 128), nn.ELU(), nn.Linear(128, o)).cuda()
 
-obs, mb = int(sys.argv[1]) if len(sys.argv) > 1 else 235, 24576
+obs, mb = int(sys.argv[1]) if len(sys.argv) > 1 else 235, int(os.environ.get("WIDE_MB", "24576"))
 actor, critic = mlp(obs, 12, 0), mlp(obs, 1, 1)
 x = torch.randn(98304, obs, device="cuda")
 rows = torch.randperm(98304, device="cuda")[:mb]
