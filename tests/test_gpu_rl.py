@@ -443,3 +443,15 @@ def _wide_mlp_check(obs, mb, gather, precision, time, WideMlpTrainer):
         ms = (time.perf_counter() - t0) * 100
         flops = 6.0 * mb * sum(p.numel() for net in (actor, critic) for p in net.parameters() if p.dim() == 2)
         print(f"wide MLP forward + backward, obs {obs}, mb {mb}, {'split-bf16' if precision else 'exact f32'}: {ms:.3f} ms = {flops / ms / 1e9:.1f} TFLOP/s (f32 MFMA peak 157)")
+
+
+def test_transposed_lds_read_mapping_matches_the_documented_one():
+    """lg_gemm.h's frag_tr builds MFMA operands with ds_read_b64_tr_b16 from a [k][feature] image; the lane mapping it assumes
+    (lane 4q+p of a 16-lane group supplies row q, columns 4p..4p+3; lane i receives column i) is checked on the device by a
+    stand-alone probe that __graft_entry__.build() compiles."""
+    import os, subprocess
+    probe = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(__file__))), "tools", "ubench", "tr16_probe")
+    if not os.path.isfile(probe):
+        pytest.skip("tools/ubench/tr16_probe not built (python -c 'import __graft_entry__ as g; g.build()')")
+    r = subprocess.run([probe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "matches the documented mapping" in r.stdout, r.stdout + r.stderr
