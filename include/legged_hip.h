@@ -254,13 +254,15 @@ int  lg_mlp_backward(const lg_mlp_net *nets, int32_t n_nets, const int64_t *rows
                      void *stream);
 
 /* The same two passes for MLPs of ANY widths (the 512-256-128 networks of anymal_c_rough / cassie / a1 / anymal_b, reference
- * legged_robot_config.py:205-208): every layer is a tiled f32-MFMA GEMM with bias / ELU / ELU' fused into its epilogue
- * (csrc/lg_gemm.h).  The activations of the forward pass stay in `workspace` (lg_mlp_wide_workspace_bytes(nets, n_nets, mb)
- * bytes) for the backward pass that follows; weight gradients are summed in a fixed order (bit-reproducible). */
+ * legged_robot_config.py:205-208).  Backward: every layer is a tiled MFMA GEMM with ELU' / bias sums fused into its epilogue
+ * (csrc/lg_gemm.h).  Forward: the same per-layer GEMMs at precision 0; at precision 1 the [235 | 169]-512-256-128-[<= 16] shapes
+ * run as ONE chain kernel (csrc/lg_policy.h: k_mlp_chain_fwd, 32 rows per workgroup through all four layers).  The activations of
+ * the forward pass stay in `workspace` (lg_mlp_wide_workspace_bytes(nets, n_nets, mb) bytes) for the backward pass that follows;
+ * weight gradients are summed in a fixed order (bit-reproducible). */
 size_t lg_mlp_wide_workspace_bytes(const lg_mlp_net *nets, int32_t n_nets, int32_t mb);
-/* Arithmetic of the lg_mlp_wide_* GEMMs: 0 = exact f32 MFMA (bitwise a k-ordered fmaf chain); 1 (default) = split-bf16, every f32
- * operand as hi + lo bf16 and every product as hi*hi + hi*lo + lo*hi with f32 accumulation (relative error of a product ~2^-15, about
- * 5 x the f32 rate).  Process-wide; returns the previous setting. */
+/* Arithmetic of the lg_mlp_wide_* kernels AND of lg_policy_act's wide actor kernel: 0 = exact f32 MFMA (bitwise a k-ordered fmaf
+ * chain); 1 (default) = split-bf16 on the bf16 matrix cores, every f32 operand as hi + lo bf16 and every product as
+ * hi*hi + hi*lo + lo*hi with f32 accumulation (relative error of a product ~2^-15).  Process-wide; returns the previous setting. */
 int  lg_mlp_wide_set_precision(int mode);
 int  lg_mlp_wide_forward(const lg_mlp_net *nets, int32_t n_nets, const int64_t *rows, int32_t mb, float *workspace, size_t workspace_bytes,
                          void *stream);

@@ -94,9 +94,11 @@ class MlpTrainer:
 
 
 class WideMlpTrainer(MlpTrainer):
-    """The same interface for MLPs of any widths (the 512-256-128 networks of the rough tasks): layer-by-layer tiled f32-MFMA GEMMs
-    (lg_mlp_wide_forward / lg_mlp_wide_backward, csrc/lg_gemm.h).  forward() leaves the activations in the workspace, the
-    backward() that follows reads them; there is no single-kernel mini-batch step for these widths (``has_fused_minibatch``)."""
+    """The same interface for MLPs of any widths (the 512-256-128 networks of the rough tasks): lg_mlp_wide_forward (one chain
+    kernel through all four layers for the compiled-in shapes, per-layer GEMMs otherwise) / lg_mlp_wide_backward (tiled dX / dW
+    GEMMs, csrc/lg_gemm.h), split-bf16 or f32 MFMA arithmetic (lg_mlp_wide_set_precision).  forward() leaves the activations in
+    the workspace, the backward() that follows reads them; there is no single-kernel mini-batch step for these widths
+    (``has_fused_minibatch``)."""
     has_fused_minibatch = False
 
     def __init__(self, nets: Sequence[nn.Sequential], inputs: Sequence[torch.Tensor], mb: int, forward_only: bool = False):
