@@ -473,12 +473,13 @@ __global__ void __launch_bounds__(256) k_gemm_wide_bf16x3(const GemmArgs G) {
 // floats) and w0p[n][0 .. K0p) likewise.  The input rows of the rough tasks are 235 / 169 floats: 940-byte strides leave every
 // 16-byte load of the GEMMs unaligned, and the row gather adds a dependent load; one copy pass per mini-batch removes both from
 // the two GEMMs that read the inputs (forward layer 0, dW of layer 0).
-struct WidePrepArgs { const float *x[2], *w[2]; float *xp[2], *wp[2]; const int64_t *rows; int d0[2], d1[2], k0p[2], mb; };
+struct WidePrepArgs { const float *x[2], *w[2]; float *xp[2], *wp[2]; const int64_t *rows; int d0[2], d1[2], k0p[2], mb; int skip_x[2]; /* the rows of this net are another net's copy */ };
 __global__ void __launch_bounds__(256) k_wide_prep(const WidePrepArgs P) {
     const int z = blockIdx.y, kp = P.k0p[z], d0 = P.d0[z], q = kp / 4;
     const size_t nx = (size_t)P.mb * q, nw = (size_t)P.d1[z] * q;
     for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < nx + nw; i += (size_t)gridDim.x * 256) {
         const bool isx = i < nx;
+        if (isx && P.skip_x[z]) continue;
         const size_t j = isx ? i : i - nx;
         const int r = (int)(j / q), c = 4 * (int)(j % q);
         const float *src = isx ? P.x[z] + (size_t)(P.rows ? P.rows[r] : r) * d0 : P.w[z] + (size_t)r * d0;

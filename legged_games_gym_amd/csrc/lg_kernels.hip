@@ -2244,6 +2244,19 @@ static void wide_layout(const lg_mlp_net &n, int mb, WideLayout &L) {
     }
     L.total = (o + 3) & ~(size_t)3;
 }
+// The gathered, padded copy of net n's input rows (k_wide_prep).  Actor and critic of the registered tasks read the SAME observation
+// tensor (no privileged observations): one copy then serves both nets -- half the gather traffic, and layer 0's dW / the chain forward
+// of the second net find the rows in cache.
+static bool wide_shared_input(const lg_mlp_net *nets, int32_t n_nets) {
+    return n_nets == 2 && nets[0].input == nets[1].input && nets[0].dims[0] == nets[1].dims[0];
+}
+static float *wide_x0p(const lg_mlp_net *nets, int32_t n_nets, int32_t mb, float *workspace, int n) {
+    float *ws = workspace;
+    const int owner = wide_shared_input(nets, n_nets) ? 0 : n;
+    for (int i = 0; i < owner; i++) { WideLayout L; wide_layout(nets[i], mb, L); ws += L.total; }
+    WideLayout L; wide_layout(nets[owner], mb, L);
+    return ws + L.x0p;
+}
 static int wide_check(const lg_mlp_net *nets, int32_t n_nets, int32_t mb) {
     if (!nets || n_nets < 1 || n_nets > 2 || mb <= 0) return fail(-1, "bad argument");
     for (int n = 0; n < n_nets; n++) {
@@ -2283,6 +2296,7 @@ int lg_mlp_wide_forward(const lg_mlp_net *nets, int32_t n_nets, const int64_t *r
         for (int n = 0; n < n_nets; n++) {
             WideLayout L; wide_layout(nets[n], mb, L);
             pr.x[n] = nets[n].input; pr.w[n] = nets[n].weights[0]; pr.xp[n] = ws + L.x0p; pr.wp[n] = ws + L.w0p;
+            pr.skip_x[n] = n > 0 && wide_shared_input(nets, n_nets);
             pr.d0[n] = nets[n].dims[0]; pr.d1[n] = nets[n].dims[1]; pr.k0p[n] = L.k0p;
             const size_t w_ = ((size_t)mb + nets[n].dims[1]) * (L.k0p / 4);
             if (w_ > work) work = w_;
@@ -2310,7 +2324,7 @@ int lg_mlp_wide_forward(const lg_mlp_net *nets, int32_t n_nets, const int64_t *r
             if (n == n_nets) ws = workspace;
             WideLayout L; wide_layout(nets[m], mb, L);
             lg::ChainNet &cn = c.net[n];
-            cn.x = ws + L.x0p; cn.ldx = L.k0p; cn.num_in = nets[m].dims[0];
+            cn.x = wide_x0p(nets, n_nets, mb, workspace, m); cn.ldx = L.k0p; cn.num_in = nets[m].dims[0];
             for (int l = 0; l < 4; l++) {
                 pk.W[n][l] = nets[m].weights[l]; pk.b[n][l] = nets[m].biases[l];
                 pk.wp[n][l] = reinterpret_cast<__bf16 *>(ws + L.wpk[l]); pk.bp[n][l] = ws + L.bpk[l];
@@ -2340,7 +2354,7 @@ int lg_mlp_wide_forward(const lg_mlp_net *nets, int32_t n_nets, const int64_t *r
             WideLayout L; wide_layout(nets[n], mb, L);
             lg::GemmNet &g = a.net[n];
             const int32_t *d = nets[n].dims;
-            g.A = l == 0 ? ws + L.x0p : ws + L.x[l]; g.lda = l == 0 ? L.k0p : d[l];
+            g.A = l == 0 ? wide_x0p(nets, n_nets, mb, workspace, n) : ws + L.x[l]; g.lda = l == 0 ? L.k0p : d[l];
             g.B = l == 0 ? ws + L.w0p : nets[n].weights[l]; g.ldb = l == 0 ? L.k0p : d[l]; g.bias = nets[n].biases[l];
             g.C = l == 3 ? nets[n].output : ws + L.x[l + 1]; g.ldc = d[l + 1];
             g.M = mb; g.N = d[l + 1]; g.K = d[l]; g.elu = l < 3; g.splits = 1; g.k_chunk = g.K;
@@ -2377,7 +2391,7 @@ int lg_mlp_wide_backward(const lg_mlp_net *nets, int32_t n_nets, const int64_t *
             lg::GemmNet &g = a.net[n];
             const int32_t *d = nets[n].dims;
             g.A = l == 3 ? nets[n].grad_output : ws + L.g[l + 1]; g.lda = d[l + 1];
-            g.B = l == 0 ? ws + L.x0p : ws + L.x[l]; g.ldb = l == 0 ? L.k0p : d[l];
+            g.B = l == 0 ? wide_x0p(nets, n_nets, mb, workspace, n) : ws + L.x[l]; g.ldb = l == 0 ? L.k0p : d[l];
             g.C = ws + L.part; g.ldc = (d[l] + 1 + 3) & ~3;
             g.M = d[l + 1]; g.N = d[l]; g.K = mb; g.splits = L.splits[l]; g.k_chunk = L.kchunk[l];
             g.tiles_m = (g.M + LG_GT - 1) / LG_GT; g.tiles_n = (d[l] + LG_GT - 1) / LG_GT;

@@ -411,7 +411,8 @@ def _wide_mlp_check(obs, mb, gather, precision, time, WideMlpTrainer):
     g = torch.Generator(device="cuda").manual_seed(5)
     x = torch.randn(R, obs, device="cuda", generator=g)
     rows = torch.randperm(R, device="cuda", generator=g)[:mb] if gather else None
-    tr = WideMlpTrainer([actor, critic], [x, x], mb)
+    xc = x if gather else x.clone()                      # same tensor: one gathered copy serves both nets; a clone: one copy per net
+    tr = WideMlpTrainer([actor, critic], [x, xc], mb)
     assert tr.supported and not tr.has_fused_minibatch
     mu, val = tr.forward(rows)
     xb = (x[rows] if gather else x[:mb]).double()
