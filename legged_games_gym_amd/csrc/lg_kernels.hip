@@ -2210,7 +2210,7 @@ int lg_ppo_minibatch(const lg_mlp_net *nets, const int64_t *rows, int32_t mb, co
 }
 
 // ---- learner kernels for the wide MLPs (lg_gemm.h): per layer a tiled f32-MFMA GEMM with the element-wise work in its epilogue
-struct WideLayout { size_t x[4], g[4], part, x0p, w0p, wpk[4], bpk[4], total; int splits[4]; int kchunk[4]; int k0p; int ks[4], ot[4]; bool chain; };      // float offsets into one net's workspace slice
+struct WideLayout { size_t x[4], g[4], part, x0p, w0p, wpk[4], bpk[4], total; int splits[4]; int kchunk[4]; int k0p; int ks[4], ot[4]; bool chain; int out_chunks; bool out_narrow; };      // float offsets into one net's workspace slice
 static void wide_layout(const lg_mlp_net &n, int mb, WideLayout &L) {
     size_t o = 0;
     for (int l = 1; l <= 3; l++) { L.x[l] = o; o += (size_t)mb * n.dims[l]; }
@@ -2228,6 +2228,9 @@ static void wide_layout(const lg_mlp_net &n, int mb, WideLayout &L) {
         const size_t p = (size_t)sp * n.dims[l + 1] * ((n.dims[l] + 1 + 3) & ~3);
         if (p > pmax) pmax = p;
     }
+    L.out_narrow = n.dims[3] == 128 && n.dims[4] <= LG_OUT_MAXN;      // k_wide_out_bwd: dX + dW of the output layer in one pass
+    L.out_chunks = mb >= 2048 ? 256 : (mb + 7) / 8;
+    if (L.out_narrow) { const size_t p = (size_t)L.out_chunks * n.dims[4] * ((n.dims[3] + 1 + 3) & ~3); if (p > pmax) pmax = p; }
     L.part = o; o += pmax;
     o = (o + 3) & ~(size_t)3;
     L.k0p = (n.dims[0] + 3) & ~3;                     // aligned, gather-free copies of the layer-0 operands (k_wide_prep)
@@ -2379,7 +2382,31 @@ int lg_mlp_wide_backward(const lg_mlp_net *nets, int32_t n_nets, const int64_t *
         for (int l = 0; l < 4; l++) if (!nets[n].grad_weights[l] || !nets[n].grad_biases[l]) return fail(-1, "null gradient pointer");
     }
     hipStream_t st = (hipStream_t)stream;
+    bool narrow = true;
+    for (int n = 0; n < n_nets; n++) { WideLayout L; wide_layout(nets[n], mb, L); narrow = narrow && L.out_narrow; }
     for (int l = 3; l >= 0; l--) {
+        if (l == 3 && narrow) {                        // the <= 16-wide output layer: G_3, dW_3, db_3 from one read of A_3 (lg_gemm.h: k_wide_out_bwd)
+            lg::OutBwdArgs o; memset(&o, 0, sizeof o);
+            lg::WideReduceArgs r; memset(&r, 0, sizeof r);
+            o.mb = mb;
+            int chunks = 0, rmax = 0;
+            float *ws = workspace;
+            for (int n = 0; n < n_nets; n++) {
+                WideLayout L; wide_layout(nets[n], mb, L);
+                const int32_t *d = nets[n].dims;
+                lg::OutBwdNet &q = o.net[n];
+                q.dz = nets[n].grad_output; q.w = nets[n].weights[3]; q.act = ws + L.x[3]; q.g = ws + L.g[3]; q.part = ws + L.part;
+                q.N = d[4]; q.K = d[3]; q.ld = (d[3] + 1 + 3) & ~3; q.chunks = L.out_chunks; q.rows_per_chunk = (mb + L.out_chunks - 1) / L.out_chunks;
+                if (q.chunks > chunks) chunks = q.chunks;
+                r.part[n] = q.part; r.gw[n] = nets[n].grad_weights[3]; r.gb[n] = nets[n].grad_biases[3];
+                r.N[n] = d[4]; r.K[n] = d[3]; r.ld[n] = q.ld; r.splits[n] = q.chunks;
+                if (d[4] * q.ld > rmax) rmax = d[4] * q.ld;
+                ws += L.total;
+            }
+            hipLaunchKernelGGL((lg::k_wide_out_bwd<LG_OUT_MAXN>), dim3(chunks, n_nets), dim3(256), 0, st, o);
+            hipLaunchKernelGGL(lg::k_wide_reduce, dim3((rmax + 255) / 256, n_nets), dim3(256), 0, st, r);
+            continue;
+        }
         // dW_l, db_l (split over the mini-batch rows) ...
         lg::GemmArgs a; memset(&a, 0, sizeof a);
         lg::WideReduceArgs r; memset(&r, 0, sizeof r);
