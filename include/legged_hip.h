@@ -256,7 +256,7 @@ int  lg_mlp_backward(const lg_mlp_net *nets, int32_t n_nets, const int64_t *rows
 /* The same two passes for MLPs of ANY widths (the 512-256-128 networks of anymal_c_rough / cassie / a1 / anymal_b, reference
  * legged_robot_config.py:205-208).  Backward: every layer is a tiled MFMA GEMM with ELU' / bias sums fused into its epilogue
  * (csrc/lg_gemm.h).  Forward: the same per-layer GEMMs at precision 0; at precision 1 the [235 | 169]-512-256-128-[<= 16] shapes
- * run as ONE chain kernel (csrc/lg_policy.h: k_mlp_chain_fwd, 32 rows per workgroup through all four layers).  The activations of
+ * run as ONE chain kernel (csrc/lg_policy.h: k_mlp_chain_fwd64, 64 rows per workgroup through all four layers).  The activations of
  * the forward pass stay in `workspace` (lg_mlp_wide_workspace_bytes(nets, n_nets, mb) bytes) for the backward pass that follows;
  * weight gradients are summed in a fixed order (bit-reproducible). */
 size_t lg_mlp_wide_workspace_bytes(const lg_mlp_net *nets, int32_t n_nets, int32_t mb);

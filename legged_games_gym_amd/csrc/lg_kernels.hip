@@ -2236,7 +2236,7 @@ static void wide_layout(const lg_mlp_net &n, int mb, WideLayout &L) {
     L.k0p = (n.dims[0] + 3) & ~3;                     // aligned, gather-free copies of the layer-0 operands (k_wide_prep)
     L.x0p = o; o += (size_t)mb * L.k0p;
     L.w0p = o; o += (size_t)n.dims[1] * L.k0p;
-    // chain forward (k_mlp_chain_fwd): split-bf16 operand streams of the four layers, re-packed every call
+    // chain forward (k_mlp_chain_fwd64): split-bf16 operand streams of the four layers, re-packed every call
     const int k0s = (n.dims[0] + 15) / 16;
     L.chain = n.dims[1] == 512 && n.dims[2] == 256 && n.dims[3] == 128 && n.dims[4] <= 16 && (k0s == 15 || k0s == 11);
     for (int l = 0; l < 4; l++) {
@@ -2316,7 +2316,7 @@ int lg_mlp_wide_forward(const lg_mlp_net *nets, int32_t n_nets, const int64_t *r
         chain = chain && L.chain && (n == 0 || L.ks[0] == k0s);
         k0s = L.ks[0];
     }
-    if (chain) {                                       // all four layers in one launch, activations on chip (lg_policy.h: k_mlp_chain_fwd)
+    if (chain) {                                       // all four layers in one launch, activations on chip (lg_policy.h: k_mlp_chain_fwd64)
         lg::ChainPackArgs pk; memset(&pk, 0, sizeof pk);
         lg::ChainArgs c; memset(&c, 0, sizeof c);
         c.mb = mb;
@@ -2342,9 +2342,9 @@ int lg_mlp_wide_forward(const lg_mlp_net *nets, int32_t n_nets, const int64_t *r
         }
         int blocks = (int)((work + 255) / 256); if (blocks > 512) blocks = 512;
         hipLaunchKernelGGL(lg::k_chain_pack, dim3(blocks, 4, n_nets), dim3(256), 0, st, pk);
-        const dim3 grid((mb + LG_PW_ENVS - 1) / LG_PW_ENVS, n_nets), block(64 * LG_PW_WAVES);
-        if (k0s == 15) hipLaunchKernelGGL((lg::k_mlp_chain_fwd<15, 16, 8, 4>), grid, block, 0, st, c);
-        else hipLaunchKernelGGL((lg::k_mlp_chain_fwd<11, 16, 8, 4>), grid, block, 0, st, c);
+        const dim3 grid((mb + 63) / 64, n_nets), block(64 * LG_PW_WAVES);                  // 64 rows per workgroup (k_mlp_chain_fwd64)
+        if (k0s == 15) hipLaunchKernelGGL((lg::k_mlp_chain_fwd64<15>), grid, block, 0, st, c);
+        else hipLaunchKernelGGL((lg::k_mlp_chain_fwd64<11>), grid, block, 0, st, c);
         HIP_TRY(hipGetLastError());
         return 0;
     }

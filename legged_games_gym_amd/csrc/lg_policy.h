@@ -297,10 +297,11 @@ __global__ void __launch_bounds__(64 * LG_PW_WAVES) k_policy_act_wide(const Poli
 }
 
 // ------------------------------------------------------------------ the same chain as the LEARNER's forward pass
-// lg_mlp_wide_forward at precision 1 for the 235/169-512-256-128 shapes: 32 mini-batch rows per workgroup walk all four layers with
-// the activations in LDS; what the backward pass needs (the post-ELU activations of the three hidden layers, f32, row-major) is
+// lg_mlp_wide_forward at precision 1 for the 235/169-512-256-128 shapes: the mini-batch rows walk all four layers with the
+// activations in LDS; what the backward pass needs (the post-ELU activations of the three hidden layers, f32, row-major) is
 // written out on the way -- 128 contiguous bytes per row and tile -- and nothing is read back.  The layer-by-layer GEMMs this
-// replaces moved every activation through HBM twice (forward: 226 us per mini-batch of 24 576 rows, both nets).
+// replaces moved every activation through HBM twice (forward: 226 us per mini-batch of 24 576 rows, both nets; a first chain
+// kernel with 32 rows per workgroup, the actor kernel's structure: 163 us; this one: 130 us).
 struct ChainNet {
     const float *x; int ldx, num_in;       // gathered, padded input rows (k_wide_prep's copy)
     const bf16x8g *wb[4]; const float *bb[4];
@@ -309,88 +310,136 @@ struct ChainNet {
 };
 struct ChainArgs { ChainNet net[2]; int mb; };
 
-template <int TPW>
-LG_DEV void chain_epilogue(const f32x16p (&acc)[TPW], const float *__restrict__ b, bf16x8g (*xout)[2][64], int o0, int lane,
-                           float *__restrict__ act_row /* this lane's row, or null */) {
-    const int h = lane >> 5;
+// 64 rows per workgroup: every weight fragment feeds TWO 32-row halves, so the L2 -> CU weight stream that bounds the chain
+// (1.16 MB per workgroup whatever the rows) is paid once per 64 rows.  A 64-row x1 (512 wide, hi + lo) alone would be 128 KB of LDS, so
+// layer 0 runs in two phases of 8 output tiles and layer 1 accumulates over the 16 k-steps each phase leaves in LDS: two 64 KB
+// buffers hold x0 | x2 and half of x1 | x3.
+template <int KS, int KTOT> struct WideStream2 {                  // one output tile, k-steps k0 .. k0+KS-1 of a layer with KTOT k-steps, two row halves
+    static constexpr int PF = (LG_PW_INFLIGHT / 2 + 1) < KS + 1 ? (LG_PW_INFLIGHT / 2 + 1) : KS + 1;     // one ring live at a time (two half-depth rings, the next segment
+                                                                                                         // requested early, measured slower: 145 vs 130 us)
+    bf16x8g wh[PF], wl[PF];
+    LG_DEV void fetch(const bf16x8g *__restrict__ w, int tile, int k0, int rot, int lane, int s) {
+        int sr = s + rot; sr = sr >= KS ? sr - KS : sr;
+        const bf16x8g *q = w + ((size_t)(tile * KTOT + k0 + sr) * 2) * 64 + lane;
+        wh[s % PF] = q[0]; wl[s % PF] = q[64];
+    }
+    LG_DEV void prime(const bf16x8g *__restrict__ w, int tile, int k0, int rot, int lane) {
 #pragma unroll
-    for (int t = 0; t < TPW; t++) {
-        const float *bo = b + 32 * (o0 + t) + 4 * h;
+        for (int s = 0; s < PF - 1; s++) if (s < KS) fetch(w, tile, k0, rot, lane, s);
+    }
+    LG_DEV void run(const bf16x8g *__restrict__ w, const bf16x8g (*xin)[2][2][64], int tile, int k0, int rot, int lane, f32x16p (&acc)[2], bool zero) {
+        if (zero) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) { acc[0][i] = 0.0f; acc[1][i] = 0.0f; }
+        }
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+            if (s + PF - 1 < KS) fetch(w, tile, k0, rot, lane, s + PF - 1);
+            int sr = s + rot; sr = sr >= KS ? sr - KS : sr;
+#pragma unroll
+            for (int hf = 0; hf < 2; hf++) {
+                const bf16x8g bh = xin[sr][hf][0][lane], bl = xin[sr][hf][1][lane];
+                acc[hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[s % PF], bh, acc[hf], 0, 0, 0);
+                acc[hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[s % PF], bl, acc[hf], 0, 0, 0);
+                acc[hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[s % PF], bh, acc[hf], 0, 0, 0);
+            }
+        }
+    }
+};
+// bias + ELU of one finished tile (both row halves): f32 activations to global (column block `tile_g`), split -> LDS k-steps 2 tile_l, 2 tile_l + 1
+LG_DEV void chain_epilogue2(const f32x16p (&acc)[2], const float *__restrict__ b, bf16x8g (*xout)[2][2][64], int tile_g, int tile_l, int lane,
+                            float *__restrict__ act0, float *__restrict__ act1 /* the lane's rows of the two halves, or null */) {
+    const int h = lane >> 5;
+    const float *bo = b + 32 * tile_g + 4 * h;
+#pragma unroll
+    for (int hf = 0; hf < 2; hf++) {
+        float *act_row = hf ? act1 : act0;
 #pragma unroll
         for (int jj = 0; jj < 2; jj++) {
             float v[8];
 #pragma unroll
-            for (int i = 0; i < 8; i++) v[i] = elu1(acc[t][8 * jj + i] + bo[8 * (2 * jj + (i >> 2)) + (i & 3)]);
+            for (int i = 0; i < 8; i++) v[i] = elu1(acc[hf][8 * jj + i] + bo[8 * (2 * jj + (i >> 2)) + (i & 3)]);
             if (act_row) {
-                float *dst = act_row + 32 * (o0 + t) + 16 * jj + 4 * h;          // features 32o + 8(2jj + j') + 4h + r
+                float *dst = act_row + 32 * tile_g + 16 * jj + 4 * h;
                 *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
                 *reinterpret_cast<float4 *>(dst + 8) = make_float4(v[4], v[5], v[6], v[7]);
             }
             bf16x8g hi, lo;
             split8(v, hi, lo);
-            xout[2 * (o0 + t) + jj][0][lane] = hi; xout[2 * (o0 + t) + jj][1][lane] = lo;
+            xout[2 * tile_l + jj][hf][0][lane] = hi; xout[2 * tile_l + jj][hf][1][lane] = lo;
         }
     }
 }
 
-template <int K0S, int H1T, int H2T, int H3T>
-__global__ void __launch_bounds__(64 * LG_PW_WAVES) k_mlp_chain_fwd(const ChainArgs C) {
+template <int K0S>                                               // hidden widths 512-256-128 (16 / 8 / 4 tiles), 8 waves
+__global__ void __launch_bounds__(64 * LG_PW_WAVES) k_mlp_chain_fwd64(const ChainArgs C) {
+    static_assert(LG_PW_WAVES == 8 && K0S <= 16, "one layer-1 tile per wave; x0 fits the 16 k-step buffer");
     const ChainNet &N = C.net[blockIdx.y];
-    constexpr int NW = LG_PW_WAVES;
-    constexpr int T1 = H1T / NW, T2 = H2T >= NW ? H2T / NW : 1, T3 = 1;
-    constexpr int KA = K0S > 2 * H2T ? K0S : 2 * H2T, KB = H1T > H3T ? 2 * H1T : 2 * H3T;
-    __shared__ bf16x8g xa[KA][2][64], xb[KB][2][64];
+    __shared__ bf16x8g bufA[16][2][2][64], bufB[16][2][2][64];     // [k-step][row half][hi/lo][lane]: x0 | x2 and half of x1 | x3 (64 KB each)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5;
-    const int wv = (wave + blockIdx.x) % NW;
-    const int r0 = (blockIdx.x * 5) % K0S, r1 = (blockIdx.x * 5) % (2 * H1T), r2 = (blockIdx.x * 5) % (2 * H2T);
-    const bool on2 = wv * T2 < H2T, on3 = wv * T3 < H3T;
-    WideStream<K0S, T1> s1;
-    s1.prime(N.wb[0], wv * T1, r0, lane);
-    int row = blockIdx.x * LG_PW_ENVS + (lane & 31);
-    const bool live = row < C.mb;
-    if (!live) row = C.mb - 1;
-    const float *o = N.x + (size_t)row * N.ldx;
-    for (int s = wave; s < K0S; s += NW) {
+    const int wv = (wave + blockIdx.x) & 7;
+    const int r0 = (blockIdx.x * 5) % K0S, r1 = (blockIdx.x * 5) & 15, r2 = (blockIdx.x * 3) & 15;
+    int row[2]; bool live[2]; float *arow[3][2];
+#pragma unroll
+    for (int hf = 0; hf < 2; hf++) {
+        row[hf] = blockIdx.x * 64 + 32 * hf + (lane & 31);
+        live[hf] = row[hf] < C.mb;
+        if (!live[hf]) row[hf] = C.mb - 1;
+#pragma unroll
+        for (int l = 0; l < 3; l++) arow[l][hf] = live[hf] ? N.act[l] + (size_t)row[hf] * N.lda[l] : nullptr;
+    }
+    WideStream2<K0S, K0S> s0;
+    s0.prime(N.wb[0], wv, 0, r0, lane);
+    for (int s = wave; s < 2 * K0S; s += LG_PW_WAVES) {           // x0 of both halves -> bufA
+        const int ks = s >> 1, hf = s & 1;
+        const float *o = N.x + (size_t)row[hf] * N.ldx;
         float v[8];
 #pragma unroll
-        for (int i = 0; i < 8; i++) { const int k = 16 * s + 8 * h + i; v[i] = k < N.num_in ? o[k] : 0.0f; }
+        for (int i = 0; i < 8; i++) { const int k = 16 * ks + 8 * h + i; v[i] = k < N.num_in ? o[k] : 0.0f; }
         bf16x8g hi, lo;
         split8(v, hi, lo);
-        xa[s][0][lane] = hi; xa[s][1][lane] = lo;
+        bufA[ks][hf][0][lane] = hi; bufA[ks][hf][1][lane] = lo;
     }
     __syncthreads();
-    f32x16p a1[T1];
-    s1.run(N.wb[0], xa, wv * T1, r0, lane, a1);
-    WideStream<2 * H1T, T2> s2;
-    if (on2) s2.prime(N.wb[1], wv * T2, r1, lane);
+    f32x16p a0[2], a1[2];
+    WideStream2<16, 32> s1;
+#pragma unroll                                                     // unrolled: only one weight ring is live at a time (a loop would carry both: 270 spills)
+    for (int ph = 0; ph < 2; ph++) {
+        s0.run(N.wb[0], bufA, 8 * ph + wv, 0, r0, lane, a0, true);                      // layer-0 tile 8 ph + wv
+        s1.prime(N.wb[1], wv, 16 * ph, r1, lane);                                       // layer-1 tile wv, this phase's 16 k-steps
+        __builtin_amdgcn_sched_barrier(0);
+        chain_epilogue2(a0, N.bb[0], bufB, 8 * ph + wv, wv, lane, arow[0][0], arow[0][1]);
+        __syncthreads();
+        s1.run(N.wb[1], bufB, wv, 16 * ph, r1, lane, a1, ph == 0);
+        if (ph == 0) s0.prime(N.wb[0], 8 + wv, 0, r0, lane);
+        __syncthreads();                                                                // bufB free again
+    }
+    WideStream2<16, 16> s2;
+    if (wv < 4) s2.prime(N.wb[2], wv, 0, r2, lane);
     __builtin_amdgcn_sched_barrier(0);
-    chain_epilogue<T1>(a1, N.bb[0], xb, wv * T1, lane, live ? N.act[0] + (size_t)row * N.lda[0] : nullptr);
+    chain_epilogue2(a1, N.bb[1], bufA, wv, wv, lane, arow[1][0], arow[1][1]);           // x2 over x0 (every wave is past layer 0)
     __syncthreads();
-    f32x16p a2[T2];
-    WideStream<2 * H2T, T3> s3;
-    if (on2) s2.run(N.wb[1], xb, wv * T2, r1, lane, a2);
-    if (on3) s3.prime(N.wb[2], wv * T3, r2, lane);
+    f32x16p a2[2];
+    WideStream2<8, 8> s3;
+    if (wv < 4) s2.run(N.wb[2], bufA, wv, 0, r2, lane, a2, true);
+    if (wave == 0) s3.prime(N.wb[3], 0, 0, 0, lane);
     __builtin_amdgcn_sched_barrier(0);
-    if (on2) chain_epilogue<T2>(a2, N.bb[1], xa, wv * T2, lane, live ? N.act[1] + (size_t)row * N.lda[1] : nullptr);
-    __syncthreads();
-    f32x16p a3[T3];
-    WideStream<2 * H3T, 1> s4;
-    if (on3) s3.run(N.wb[2], xa, wv * T3, r2, lane, a3);
-    if (wave == 0) s4.prime(N.wb[3], 0, 0, lane);
-    __builtin_amdgcn_sched_barrier(0);
-    if (on3) chain_epilogue<T3>(a3, N.bb[2], xb, wv * T3, lane, live ? N.act[2] + (size_t)row * N.lda[2] : nullptr);
+    if (wv < 4) chain_epilogue2(a2, N.bb[2], bufB, wv, wv, lane, arow[2][0], arow[2][1]);
     __syncthreads();
     if (wave != 0) return;
-    f32x16p y[1];
-    s4.run(N.wb[3], xb, 0, 0, lane, y);
-    if (!live) return;
+    f32x16p y[2];
+    s3.run(N.wb[3], bufB, 0, 0, 0, lane, y, true);
 #pragma unroll
-    for (int ii = 0; ii < 2; ii++)
+    for (int hf = 0; hf < 2; hf++) {
+        if (!live[hf]) continue;
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int a = 8 * ii + 4 * h + r;                      // register i = 4ii + r of lane (row, h) is output 8ii + 4h + r
-            if (a < N.out_dim) N.out[(size_t)row * N.out_dim + a] = y[0][4 * ii + r] + N.bb[3][a];
-        }
+        for (int ii = 0; ii < 2; ii++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int a = 8 * ii + 4 * h + r;
+                if (a < N.out_dim) N.out[(size_t)row[hf] * N.out_dim + a] = y[hf][4 * ii + r] + N.bb[3][a];
+            }
+    }
 }
 
 // torch Linear [out, in] f32 -> the operand stream above; `first` selects the natural k order of layer 0
