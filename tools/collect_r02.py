@@ -42,3 +42,4 @@ with open(os.path.join(DST, "r02_training.txt"), "w") as f:
             elif line.startswith(("total", "eval")):
                 f.write(line[:300].rstrip() + "\n")
 print(sorted(x for x in os.listdir(DST) if x.startswith("r02")))
+print("note: the longer runs at the end of r02_training.txt (tools/train_probe.py 1500 anymal_c_flat / 1000 anymal_c_rough) are appended by hand")
