@@ -323,7 +323,7 @@ def test_kernel_update_with_fixed_schedule_keeps_the_learning_rate():
     assert all(bool(torch.isfinite(p).all()) for p in ac.parameters())
 
 
-def _dp_worker(rank, world, port, out):
+def _dp_worker(rank, world, port, out, obs=48, hidden=(128, 64, 32)):
     """One data-parallel rank of the KERNEL update (learner kernels + lg_adam_step, one flat all-reduce per mini-batch step) on the
     shared test GPU; gloo stands in for RCCL (two ranks cannot share one device under RCCL)."""
     import os
@@ -333,13 +333,16 @@ def _dp_worker(rank, world, port, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     torch.manual_seed(0)
-    ac = ActorCritic(48, 48, 12, actor_hidden_dims=[128, 64, 32], critic_hidden_dims=[128, 64, 32])
+    from legged_games_gym_amd import capi
+    capi.load_library().lg_mlp_wide_set_precision(0)      # exact f32 products: the first Adam step is lr * sign(g) wherever |g| is tiny,
+                                                           # so the single-process comparison below needs gradients equal to rounding
+    ac = ActorCritic(obs, obs, 12, actor_hidden_dims=list(hidden), critic_hidden_dims=list(hidden))
     alg = PPO(ac, num_learning_epochs=1, num_mini_batches=1, schedule="adaptive", desired_kl=0.01, learning_rate=1e-3, entropy_coef=0.01, device="cuda:0")
     T, N = 8, 256
-    alg.init_storage(N, T, [48], [None], [12])
+    alg.init_storage(N, T, [obs], [None], [12])
     snaps = []
     for it in range(4):
-        _storage(T=T, N=N, seed=100 * it + rank, st=alg.storage)
+        _storage(T=T, N=N, seed=100 * it + rank, st=alg.storage, obs=obs)
         alg.storage.compute_returns(torch.zeros(N, 1, device="cuda"), 0.99, 0.95)
         perm = torch.randperm(T * N, device="cuda", generator=torch.Generator(device="cuda").manual_seed(it))
         alg.update(perm=perm)
@@ -349,34 +352,41 @@ def _dp_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_data_parallel_kernel_update_two_ranks_one_gpu(tmp_path):
-    """the N > 1 update on the kernel path.  Two gloo ranks on the one GPU: (i) replicas stay BIT-identical over 4
+@pytest.mark.parametrize("obs,hidden", [(48, (128, 64, 32)), (235, (512, 256, 128))])
+def test_data_parallel_kernel_update_two_ranks_one_gpu(tmp_path, obs, hidden):
+    """the N > 1 update on the kernel path, for the flat networks (lg_ppo_minibatch) and for the wide ones of config 4
+    (lg_mlp_wide_*: the 8 x 4096 anymal_c_rough case).  Two gloo ranks on the one GPU: (i) replicas stay BIT-identical over 4
     updates (the gradients come out of one all-reduced flat buffer on both), (ii) the first update equals the single-process update on
     the concatenated batch (mean of the two shards' gradients and KLs, global advantage normalisation through the all-gather)."""
     import socket
     import torch.multiprocessing as mp
     from legged_games_gym_amd.rl import ActorCritic, PPO
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    mp.spawn(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_dp_worker, args=(2, port, str(tmp_path), obs, hidden), nprocs=2, join=True)
     r0 = torch.load(tmp_path / "r0.pt", weights_only=True); r1 = torch.load(tmp_path / "r1.pt", weights_only=True)
     assert r0["flat"] and r1["flat"]                                     # the kernel path with the flat gradient buffer was the one that ran
     for a, b in zip(r0["snaps"], r1["snaps"]):
         for x, y in zip(a, b):
             assert torch.equal(x, y)
     # single process, both shards as one batch of 512 envs (first update only: later ones start from different storages per rank)
+    from legged_games_gym_amd import capi
+    prev = capi.load_library().lg_mlp_wide_set_precision(0)
     torch.manual_seed(0)
-    ac = ActorCritic(48, 48, 12, actor_hidden_dims=[128, 64, 32], critic_hidden_dims=[128, 64, 32])
+    ac = ActorCritic(obs, obs, 12, actor_hidden_dims=list(hidden), critic_hidden_dims=list(hidden))
     alg = PPO(ac, num_learning_epochs=1, num_mini_batches=1, schedule="adaptive", desired_kl=0.01, learning_rate=1e-3, entropy_coef=0.01, device="cuda:0")
     T, N = 8, 256
-    alg.init_storage(2 * N, T, [48], [None], [12])
-    a, b = _storage(T=T, N=N, seed=0), _storage(T=T, N=N, seed=1)
+    alg.init_storage(2 * N, T, [obs], [None], [12])
+    a, b = _storage(T=T, N=N, seed=0, obs=obs), _storage(T=T, N=N, seed=1, obs=obs)
     for name in ("observations", "actions", "rewards", "dones", "values", "actions_log_prob", "mu", "sigma"):
         getattr(alg.storage, name).copy_(torch.cat((getattr(a, name), getattr(b, name)), dim=1))
     alg.storage.step = T
     alg.storage.compute_returns(torch.zeros(2 * N, 1, device="cuda"), 0.99, 0.95)
     alg.update()
+    capi.load_library().lg_mlp_wide_set_precision(prev)
     for want, got in zip(alg.actor_critic.parameters(), r0["snaps"][0]):
-        assert torch.allclose(want.detach().cpu(), got, rtol=2e-4, atol=2e-6), float((want.detach().cpu() - got).abs().max())
+        d = (want.detach().cpu() - got).abs()
+        # equal up to summation order; a handful of elements whose gradient is at rounding level may take the step the other way (2 lr)
+        assert float((d > 2e-6 + 2e-4 * got.abs()).float().mean()) < 1e-3 and float(d.max()) <= 2.1e-3, (float(d.max()), float((d > 2e-6).float().mean()))
     assert abs(alg.learning_rate - float(r0["snaps"][0][-1])) < 1e-9
 
 
