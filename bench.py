@@ -407,9 +407,13 @@ def training_leg(a, iters, rank, local_rank, world, coll_dev, ranks_seen, backen
            "final_learning_rate": float(alg.learning_rate),
            "note": "includes re-capturing the rollout graph at the start of the timed learn() call"}
     if world > 1:
-        out["collectives_per_iteration"] = {"all_gather_returns_advantages": 1, "gradient_all_reduce": alg.num_learning_epochs * alg.num_mini_batches,
-                                            "kl_all_reduce": alg.num_learning_epochs * alg.num_mini_batches if alg.schedule == "adaptive" else 0,
-                                            "backend": "nccl (RCCL)" if backend == "nccl" else backend, "ranks": ranks_seen}
+        steps = alg.num_learning_epochs * alg.num_mini_batches
+        if getattr(alg, "_gflat", None) is not None:      # kernel path: every .grad is a view of one buffer whose last slot carries the KL
+            coll = {"all_gather_returns_advantages": 1, "flat_all_reduce_all_gradients_and_kl": steps}
+        else:
+            coll = {"all_gather_returns_advantages": 1, "gradient_all_reduce": steps, "kl_all_reduce": steps if alg.schedule == "adaptive" else 0}
+        coll.update({"backend": "nccl (RCCL)" if backend == "nccl" else backend, "ranks": ranks_seen})
+        out["collectives_per_iteration"] = coll
     return out
 
 

@@ -37,5 +37,6 @@ def test_gpus_2_spawns_two_ranks_and_reports_the_collectives():
     assert out["n_gpus"] == 2 and out["gloo_ranks"] == 2 and out["config"]["parallelism"] == "env-sharded x2"
     tr = out["ppo_training"]
     assert "error" not in tr and tr["collectives_per_iteration"]["ranks"] == 2
-    assert tr["collectives_per_iteration"]["all_gather_returns_advantages"] == 1 and tr["collectives_per_iteration"]["gradient_all_reduce"] == 20
+    # kernel update path: ONE collective per mini-batch step (all gradients + the KL in one flat buffer), one all-gather per iteration
+    assert tr["collectives_per_iteration"]["all_gather_returns_advantages"] == 1 and tr["collectives_per_iteration"]["flat_all_reduce_all_gradients_and_kl"] == 20
     assert tr["value"] > 0 and out["value"] > 0
