@@ -123,7 +123,7 @@ def _update_path(alg):
         return "torch autograd"
     if getattr(tr, "has_fused_minibatch", False):
         return "lg_ppo_minibatch: forward + PPO loss + backward in one f32-MFMA kernel (v_mfma_f32_16x16x4_f32), lg_adam_step; one HIP graph per update"
-    return ("wide learner kernels: chain forward k_mlp_chain_fwd + tiled dX / dW GEMMs, split-bf16 products (hi*hi + hi*lo + lo*hi, f32 accumulate) "
+    return ("wide learner kernels: chain forward k_mlp_chain_fwd64 + tiled dX / dW GEMMs (ds_read_b64_tr_b16 operand staging), split-bf16 products (hi*hi + hi*lo + lo*hi, f32 accumulate) "
             "on v_mfma_f32_32x32x16_bf16 (lg_mlp_wide_set_precision(1), the default; 0 = f32 MFMA), lg_ppo_loss, lg_adam_step")
 
 
