@@ -189,15 +189,17 @@ def test_fused_policy_step_equals_actor_kernel_plus_step():
         env2.step_policy(actor)
 
 
-def test_two_rank_training_on_one_gpu(tmp_path):
+@pytest.mark.parametrize("task", ["anymal_c_flat", "anymal_c_rough"])
+def test_two_rank_training_on_one_gpu(tmp_path, task):
     """scripts/train.py under torch.distributed.run: 2 ranks (sharing cuda:0 here, gloo instead of RCCL) shard the envs, rank 0's
-    weights are broadcast, the PPO collectives keep the replicas in step, rank 0 alone logs.  Rehearsal of the 8-GPU launch."""
+    weights are broadcast, the PPO collectives keep the replicas in step, rank 0 alone logs.  Rehearsal of the 8-GPU launch, for the
+    flat task and for config 4's task (anymal_c_rough: height field, wide actor / learner kernels)."""
     import os, socket, subprocess, sys
     sck = socket.socket(); sck.bind(("127.0.0.1", 0)); port = sck.getsockname()[1]; sck.close()
     repo = os.path.dirname(os.path.dirname(os.path.realpath(__file__)))
     env = dict(os.environ, LG_LOCAL_DEVICE="0", LG_DIST_BACKEND="gloo", PYTHONPATH=repo, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           "-m", "legged_games_gym_amd.scripts.train", "--task=anymal_c_flat", "--headless", "--num_envs", "256", "--max_iterations", "3"]
+           "-m", "legged_games_gym_amd.scripts.train", f"--task={task}", "--headless", "--num_envs", "256", "--max_iterations", "3"]
     r = subprocess.run(cmd, cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("it ")]
