@@ -2467,7 +2467,8 @@ int lg_rollout_record(const lg_rollout_step *s, void *stream) {
                      s->std, s->storage_sigma, s->storage_log_prob, s->num_envs, s->num_obs, s->num_actions};
     if (s->std && (!s->storage_sigma || !s->storage_log_prob)) return fail(-1, "std given without storage_sigma / storage_log_prob");
     const int64_t n = (int64_t)s->num_envs * s->num_obs;
-    hipLaunchKernelGGL(lg::k_rollout_record, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    if (s->num_actions > 16) return fail(-1, "lg_rollout_record: at most 16 actions");
+    hipLaunchKernelGGL(lg::k_rollout_record, dim3((unsigned)((n + 255) / 256 + ((int64_t)s->num_envs * 16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }

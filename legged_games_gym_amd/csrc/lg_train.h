@@ -674,25 +674,36 @@ struct RecordArgs {
     int32_t num_envs, num_obs, num_actions;
 };
 __global__ void __launch_bounds__(256) k_rollout_record(const RecordArgs A) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (int64_t)A.num_envs * A.num_obs) return;
-    const int env = (int)(i / A.num_obs), k = (int)(i % A.num_obs);
-    A.st_obs[i] = A.obs[i];
-    if (k < A.num_actions) {
-        const size_t j = (size_t)env * A.num_actions + k;
-        A.st_actions[j] = A.actions[j]; A.st_mu[j] = A.mean[j];
-    }
-    if (k != 0) return;
-    if (A.std) {                                       // Normal(mean, std).log_prob(action).sum(-1) and the broadcast std, as PPO.act stores them
-        float lp = 0.0f;
-        for (int a = 0; a < A.num_actions; a++) {
-            const size_t j = (size_t)env * A.num_actions + a;
-            const float sg = A.std[a], z = (A.actions[j] - A.mean[j]) / sg;
-            lp += -0.5f * z * z - __logf(sg) - 0.918938533f;
-            A.st_sigma[j] = sg;
+    // blocks [0, nb_copy): one element of the observation copy per thread (+ the action / mean copies on the first num_actions lanes of an env);
+    // blocks [nb_copy, ...): the per-env bookkeeping on 16 lanes per env -- lane a owns action a's log-prob term, a 16-lane butterfly sums
+    // them (one thread per env walking the actions serially was a ~100-instruction chain of dependent loads: the kernel's 10 us)
+    const int64_t n_copy = (int64_t)A.num_envs * A.num_obs;
+    const int nb_copy = (int)((n_copy + 255) / 256);
+    if ((int)blockIdx.x < nb_copy) {
+        const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        if (i >= n_copy) return;
+        const int env = (int)(i / A.num_obs), k = (int)(i % A.num_obs);
+        A.st_obs[i] = A.obs[i];
+        if (k < A.num_actions) {
+            const size_t j = (size_t)env * A.num_actions + k;
+            A.st_actions[j] = A.actions[j]; A.st_mu[j] = A.mean[j];
         }
-        A.st_log_prob[env] = lp;
+        return;
     }
+    const int t = ((int)blockIdx.x - nb_copy) * 256 + threadIdx.x, env_raw = t >> 4, a = t & 15;
+    const bool live = env_raw < A.num_envs;
+    const int env = live ? env_raw : A.num_envs - 1;
+    float term = 0.0f;
+    if (A.std && a < A.num_actions) {                  // Normal(mean, std).log_prob(action).sum(-1) and the broadcast std, as PPO.act stores them
+        const size_t j = (size_t)env * A.num_actions + a;
+        const float sg = A.std[a], z = (A.actions[j] - A.mean[j]) / sg;
+        term = -0.5f * z * z - __logf(sg) - 0.918938533f;
+        if (live) A.st_sigma[j] = sg;
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) term += __shfl_xor(term, o);      // within the env's 16 lanes (aligned: 256 threads = 16 envs per block)
+    if (!live || a != 0) return;
+    if (A.std) A.st_log_prob[env] = term;
     const float r = A.rewards[env];
     const uint8_t d = A.dones[env];
     A.st_rewards[env] = r; A.st_dones[env] = d;
