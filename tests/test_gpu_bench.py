@@ -40,3 +40,15 @@ def test_gpus_2_spawns_two_ranks_and_reports_the_collectives():
     # kernel update path: ONE collective per mini-batch step (all gradients + the KL in one flat buffer), one all-gather per iteration
     assert tr["collectives_per_iteration"]["all_gather_returns_advantages"] == 1 and tr["collectives_per_iteration"]["flat_all_reduce_all_gradients_and_kl"] == 20
     assert tr["value"] > 0 and out["value"] > 0
+
+
+@pytest.mark.parametrize("task,envs,contact", [("anymal_c_rough", 4096, "height-field contact"), ("cassie", 8192, "height-field contact")])
+def test_bench_lines_of_configs_3_and_5(task, envs, contact):
+    """BASELINE.json configs 3 and 5 through bench.py: default env counts (8192 for cassie), height-field contact unless --trimesh, the
+    wide actor kernel in the graph, finite state, and a PPO leg on the wide learner kernels."""
+    out = _run(["--task", task, "--steps", "40", "--warmup", "20", "--no-cpu-baseline", "--training-iters", "2"])
+    assert out["config"]["envs_per_gpu"] == envs and contact in out["config"]["workload"] and out["config"]["state_finite"]
+    assert "k_policy_act_wide" in out["config"]["policy"] and out["value"] > 1e7
+    assert 0.0 < out["roofline"]["frac"] < 1.0 and out["roofline"]["algorithmic_bytes_per_env_step"] > 1000
+    tr = out["ppo_training"]
+    assert "error" not in tr and tr["value"] > 1e6 and "wide learner kernels" in tr["update_path"]
