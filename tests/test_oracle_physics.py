@@ -361,6 +361,31 @@ def test_self_collision_pushes_crossed_legs_apart(oracle_lib):
     assert np.abs(cf0).max() == 0.0 and abs(qd0[0, lf]) < 0.05
 
 
+def test_self_collision_exchanges_momentum_between_the_links_only(oracle_lib):
+    """Newton's third law for the self-collision pairs: one front leg is swung into the other in flight.  The two bodies sit on different
+    lanes and each side folds in its own implicit estimate of the pair force (mass-ratio weighted block Jacobi), so the
+    scheme is not conservative by construction -- measured: the robot's total linear / angular momentum changes by 0.6 % / 0.4 % of the
+    impulse the two legs exchange (1.7 N s); asserted below 2 %."""
+    cfg, robot, p, o = sim("anymal_c_flat", 2, tweak=lambda c: setattr(c.asset, "self_collisions", 0))
+    airborne(o)
+    q0 = np.array(list(p.default_dof_pos)[:12], np.float64)
+    q, sign, (lf, rf) = _crossing_pose(robot, q0)
+    dof = o.buf["dof_state"].reshape(2, 12, 2)
+    dof[:, :, 0] = q; dof[:, :, 1] = 0.0
+    dof[:, lf, 1] = sign[lf] * 2.0                                   # the left leg moves into the right one
+    o.buf["root_states"][:, 3:7] = [0, 0, 0, 1]; o.buf["root_states"][:, 7:13] = 0.0
+    state = lambda: (o.buf["root_states"][0], o.buf["dof_state"][0:12])
+    P0, L0 = _momentum(robot, *state()), _angular_momentum_about_com(robot, *state())
+    impulse = 0.0
+    for s in range(1, 21):
+        o.physics_substep(np.zeros((2, 12), np.float32), True)
+        impulse += float(np.linalg.norm(o.buf["contact_forces"][0], axis=1).max()) * p.sim_dt
+    assert impulse > 0.5                                             # the legs did collide
+    dP = _momentum(robot, *state()) - (P0 + np.array([0, 0, -robot.total_mass * G * 20 * p.sim_dt]))
+    dL = _angular_momentum_about_com(robot, *state()) - L0
+    assert np.abs(dP[:2]).max() < 0.02 * impulse and np.abs(dL).max() < 0.02 * impulse, (dP, dL, impulse)
+
+
 def adversarial_actions(robot, p, N, seed=0):
     """All four HAA joints swing towards the body's mid-plane, the knees fold: legs are driven into each other and into the trunk."""
     q0 = np.array(list(p.default_dof_pos)[:12], np.float64)
