@@ -28,6 +28,7 @@ import socket
 import statistics
 import subprocess
 import sys
+import threading
 import time
 
 REPO = os.path.dirname(os.path.realpath(__file__))
@@ -300,16 +301,7 @@ def worker(a):
         except Exception as exc:
             sc_cost = {"error": f"{type(exc).__name__}: {exc}"}
 
-    training = None
-    iters = a.training_iters if a.training_iters >= 0 else (100 if a.task == "anymal_c_flat" else 20)
-    if iters > 0:
-        try:                                     # extra information, never allowed to take the headline line down
-            training = training_leg(a, iters, rank, local_rank, world, coll_dev, ranks_seen, backend)
-        except Exception as exc:
-            if world > 1:
-                raise                            # a rank that skips the leg would leave the others inside a collective
-            training = {"error": f"{type(exc).__name__}: {exc}"}
-
+    out = None
     if rank == 0:
         from tools.flop_count import flops_per_env_step
         total_envs = a.num_envs * world
@@ -357,12 +349,50 @@ def worker(a):
             out["self_collision"] = sc_cost
         if world > 1:
             out["rccl_ranks" if backend == "nccl" else f"{backend}_ranks"] = ranks_seen
+
+    # The PPO leg is extra information and is never allowed to take the headline line down.  At N > 1 it contains collectives, so
+    # a rank that fails or stalls inside it would leave the others waiting: every rank runs it under a watchdog, and after a
+    # failure no further collective is attempted -- rank 0 prints the line it already holds (with the error) and the ranks leave.
+    printed = threading.Lock()
+
+    def emit(training):
+        if rank != 0 or not printed.acquire(blocking=False):
+            return
         if training is not None:
             out["ppo_training"] = training
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a)
-        print(json.dumps(out), flush=True)
+        sys.__stdout__.write(json.dumps(out) + "\n")         # (the watchdog may fire while the leg has sys.stdout redirected)
+        sys.__stdout__.flush()
+
+    training, broken = None, False
+    iters = a.training_iters if a.training_iters >= 0 else (100 if a.task == "anymal_c_flat" else 20)
+    if iters > 0:
+        limit = float(os.environ.get("LG_BENCH_PPO_TIMEOUT_S", "300"))
+        finished = threading.Event()
+
+        def abandon():
+            if finished.is_set():
+                return
+            emit({"error": f"PPO leg did not finish within {limit:g} s at world size {world}: abandoned, headline line unaffected"})
+            sys.stdout.flush()
+            os._exit(0)
+        timer = threading.Timer(limit, abandon)
+        timer.daemon = True
+        if world > 1:
+            timer.start()
+        try:
+            training = training_leg(a, iters, rank, local_rank, world, coll_dev, ranks_seen, backend)
+        except Exception as exc:
+            training, broken = {"error": f"{type(exc).__name__}: {exc}"}, world > 1
+        finally:
+            finished.set()
+            timer.cancel()
+    emit(training)
     if world > 1:
+        if broken:                               # the other ranks may still sit in a collective of the leg: do not join them again
+            sys.stdout.flush()
+            os._exit(0)
         dist.barrier()
         dist.destroy_process_group()
 
@@ -383,6 +413,11 @@ def training_leg(a, iters, rank, local_rank, world, coll_dev, ranks_seen, backen
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+    fault = os.environ.get("LG_BENCH_PPO_FAULT", "")             # test hook (tests/test_gpu_bench.py): "raise:<rank>" / "hang:<rank>"
+    if fault and int(fault.split(":")[1]) == rank:
+        if fault.startswith("raise"):
+            raise RuntimeError("injected PPO-leg failure")
+        time.sleep(3600)
     with contextlib.redirect_stdout(io.StringIO()):              # rank 0 prints ONE line: everything here stays silent
         args = get_args(["--task", a.task, "--headless", "--sim_device", f"cuda:{local_rank}", "--rl_device", f"cuda:{local_rank}", "--num_envs", str(a.num_envs)])
         env_cfg, train_cfg = task_registry.get_cfgs(a.task)

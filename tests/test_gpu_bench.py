@@ -52,3 +52,13 @@ def test_bench_lines_of_configs_3_and_5(task, envs, contact):
     assert 0.0 < out["roofline"]["frac"] < 1.0 and out["roofline"]["algorithmic_bytes_per_env_step"] > 1000
     tr = out["ppo_training"]
     assert "error" not in tr and tr["value"] > 1e6 and "wide learner kernels" in tr["update_path"]
+
+
+@pytest.mark.parametrize("fault", ["raise:1", "hang:1"])
+def test_a_failing_ppo_leg_at_world_2_leaves_the_headline_line(fault):
+    """The PPO leg holds the collectives of the N > 1 line; a rank that raises or stalls in it must not cost the headline: rank 0 still
+    prints its ONE line, with the error recorded in `ppo_training`, and every rank exits (no rank left inside a collective)."""
+    out = _run(["--gpus", "2", "--steps", "40", "--warmup", "20", "--num-envs", "512", "--no-cpu-baseline", "--training-iters", "2"],
+               env={"LG_BENCH_BACKEND": "gloo", "LG_BENCH_PPO_FAULT": fault, "LG_BENCH_PPO_TIMEOUT_S": "20"})
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["gloo_ranks"] == 2
+    assert "error" in out["ppo_training"]
