@@ -488,17 +488,33 @@ __global__ void __launch_bounds__(256) k_wide_prep(const WidePrepArgs P) {
     }
 }
 
-// dW / db from the per-split partials [splits][N][K + 1] in a fixed order: gw[n][k] (torch layout), gb[n]
-struct WideReduceArgs { const float *part[2]; float *gw[2], *gb[2]; int N[2], K[2], ld[2], splits[2]; };     // ld: row stride of a partial (K + 1 rounded up to 4)
+// dW / db from the per-split partials [splits][N][K + 1] in a fixed order: gw[n][k] (torch layout), gb[n].  `group` lanes share one
+// element (lane q sums the splits q, q + group, ... in order, then a fixed xor butterfly): 1 for the big layers (coalesced, bandwidth-bound),
+// 8 for the narrow output layer, whose 256 chunks x 1.6 k elements are pure load latency (12.9 us with one lane per element and 8 loads
+// in flight, 8.0 us with 16).  Either way the order of the additions is fixed: the gradients are bit-reproducible.
+struct WideReduceArgs { const float *part[2]; float *gw[2], *gb[2]; int N[2], K[2], ld[2], splits[2]; int group; };     // ld: row stride of a partial (K + 1 rounded up to 4)
 __global__ void __launch_bounds__(256) k_wide_reduce(const WideReduceArgs R) {
-    const int z = blockIdx.y, N = R.N[z], K = R.K[z], ld = R.ld[z];
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= N * ld) return;
-    const int n = i / ld, k = i % ld;
-    if (k > K) return;
+    const int z = blockIdx.y, N = R.N[z], K = R.K[z], ld = R.ld[z], G = R.group;
+    const int t = blockIdx.x * 256 + threadIdx.x, i = t / G, q = t % G;
+    const bool in = i < N * ld;                     // (whole groups are in or out: 256 is a multiple of G)
+    const int n = in ? i / ld : 0, k = in ? i % ld : 0;
     float s = 0.0f;
-#pragma unroll 8                                   // same order of additions; eight independent loads in flight instead of one
-    for (int p = 0; p < R.splits[z]; p++) s += R.part[z][(size_t)p * N * ld + i];
+    if (in && k <= K) {
+        const size_t stride = (size_t)N * ld;
+        const float *src = R.part[z] + i;
+        const int S = R.splits[z];
+        int p = q;
+        for (; p + 15 * G < S; p += 16 * G) {       // 16 independent loads in flight
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) v[u] = src[(size_t)(p + u * G) * stride];
+#pragma unroll
+            for (int u = 0; u < 16; u++) s += v[u];
+        }
+        for (; p < S; p += G) s += src[(size_t)p * stride];
+    }
+    for (int o = 1; o < G; o <<= 1) s += __shfl_xor(s, o);
+    if (!in || k > K || q != 0) return;
     if (k < K) R.gw[z][(size_t)n * K + k] = s;
     else R.gb[z][n] = s;
 }

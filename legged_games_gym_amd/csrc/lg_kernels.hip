@@ -2404,7 +2404,8 @@ int lg_mlp_wide_backward(const lg_mlp_net *nets, int32_t n_nets, const int64_t *
                 ws += L.total;
             }
             hipLaunchKernelGGL((lg::k_wide_out_bwd<LG_OUT_MAXN>), dim3(chunks, n_nets), dim3(256), 0, st, o);
-            hipLaunchKernelGGL(lg::k_wide_reduce, dim3((rmax + 255) / 256, n_nets), dim3(256), 0, st, r);
+            r.group = 8;
+            hipLaunchKernelGGL(lg::k_wide_reduce, dim3((rmax * r.group + 255) / 256, n_nets), dim3(256), 0, st, r);
             continue;
         }
         // dW_l, db_l (split over the mini-batch rows) ...
@@ -2430,6 +2431,7 @@ int lg_mlp_wide_backward(const lg_mlp_net *nets, int32_t n_nets, const int64_t *
             ws += L.total;
         }
         LAUNCH_WIDE(lg::GEMM_DW, dim3(gx, gy, n_nets), a)
+        r.group = 1;
         hipLaunchKernelGGL(lg::k_wide_reduce, dim3((rmax + 255) / 256, n_nets), dim3(256), 0, st, r);
         if (l == 0) break;
         // ... and G_l = (G_{l+1} W_l) * elu'(X_l)

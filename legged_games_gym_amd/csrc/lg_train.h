@@ -259,6 +259,9 @@ __global__ void __launch_bounds__(64 * LG_TRAIN_WAVES * SLOTS) k_mlp_train(const
     unsigned long long *tr = (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ? A.trace : nullptr;
     int tri = 0;
 #define LG_TR() do { if (tr && tri < 60) tr[tri++] = __builtin_readcyclecounter(); } while (0)
+    // (diagnostic) every workgroup also leaves its start / end on the 100 MHz wall clock behind the 64 stamps: [64 + 2 * wg], [65 + 2 * wg]
+    unsigned long long *wgclk = (A.trace && threadIdx.x == 0) ? A.trace + 64 + 2 * (blockIdx.y * gridDim.x + blockIdx.x) : nullptr;
+    if (wgclk) wgclk[0] = wall_clock64();
     LG_TR();
     const MlpNetArgs &N = A.net[blockIdx.y];
     // role of this wave within its group, rotated by the group index: the thin layers (2 and 1 output tiles) land on different SIMDs
@@ -478,6 +481,7 @@ __global__ void __launch_bounds__(64 * LG_TRAIN_WAVES * SLOTS) k_mlp_train(const
         case 2: row_tiles(std::integral_constant<int, 2>{}); break;
         default: row_tiles(std::integral_constant<int, 3>{}); break;
     }
+    if (tr) { tr[61] = wgclk[0]; tr[62] = wall_clock64(); }      // (diagnostic) wall clock at the start and at the end of the row-tile loop
     // The groups of a workgroup fold their accumulators through LDS (the activation areas are free now) in group order, so each
     // workgroup writes ONE partial: half the workspace traffic and half the work of k_mlp_reduce with 2 groups.
     if (BWD) {
@@ -541,6 +545,8 @@ __global__ void __launch_bounds__(64 * LG_TRAIN_WAVES * SLOTS) k_mlp_train(const
         train_flush<D3T, 1>(a3, part, d3, d4, wave, lane);
     }
     LG_TR();
+    if (wgclk) wgclk[1] = wall_clock64();
+    if (tr) tr[63] = wgclk[1];
 #undef LG_TR
 }
 

@@ -38,9 +38,9 @@ if os.environ.get("TRACE"):
     import ctypes as C
     lib = tr.lib
     for name, fn in (("forward", lambda: tr.forward(rows)), ("backward", lambda: tr.backward(rows))):
-        buf = torch.zeros(64, dtype=torch.int64, device="cuda")
+        buf = torch.zeros(64 + 2 * 1024, dtype=torch.int64, device="cuda")
         lib.lg_mlp_trace(buf.data_ptr()); fn(); torch.cuda.synchronize(); lib.lg_mlp_trace(None)
-        t = buf.cpu().tolist(); t = [v for v in t if v]
+        t = buf.cpu().tolist()[:60]; t = [v for v in t if v]
         print(name, "stamps:", len(t), "deltas (s_memtime ticks):", [t[i + 1] - t[i] for i in range(len(t) - 1)], "total", t[-1] - t[0])
 
 # fused mini-batch kernel (forward + PPO loss + backward): timing and phase trace
@@ -56,7 +56,20 @@ b.clip, b.value_coef, b.entropy_coef, b.use_clipped_value, b.d_std, b.stats = 0.
 tm = timeit(lambda: tr.ppo_minibatch(rows, b))
 print(f"mb {mb}: lg_ppo_minibatch (forward + loss + backward + reduce) {tm:.1f} us ({3 * flops_fwd / tm / 1e6:.1f} TFLOP/s)")
 if os.environ.get("TRACE"):
-    buf = torch.zeros(64, dtype=torch.int64, device="cuda")
+    buf = torch.zeros(64 + 2 * 1024, dtype=torch.int64, device="cuda")
     tr.lib.lg_mlp_trace(buf.data_ptr()); tr.ppo_minibatch(rows, b); torch.cuda.synchronize(); tr.lib.lg_mlp_trace(None)
-    t = [v for v in buf.cpu().tolist() if v]
+    raw = buf.cpu().tolist()
+    t = [v for v in raw[:60] if v]
     print("ppo_minibatch stamps:", len(t), "deltas:", [t[i + 1] - t[i] for i in range(len(t) - 1)], "total", t[-1] - t[0])
+    print(f"workgroup (0,0) on the wall clock: row-tile loop ends {(raw[62] - raw[61]) / 100.0:.2f} us after its start, kernel body ends at {(raw[63] - raw[61]) / 100.0:.2f} us")
+    import numpy as np
+    wg = np.array(raw[64:], dtype=np.int64).reshape(-1, 2)
+    wg = wg[wg[:, 0] > 0]
+    t0 = wg[:, 0].min()
+    st, en = (wg[:, 0] - t0) / 100.0, (wg[:, 1] - t0) / 100.0            # 100 MHz wall clock -> us
+    print(f"workgroups {len(wg)}: start us median {np.median(st):.2f} max {st.max():.2f};  end us min {en.min():.2f} median {np.median(en):.2f} "
+          f"p90 {np.percentile(en, 90):.2f} max {en.max():.2f};  own duration median {np.median(en - st):.2f} max {(en - st).max():.2f}")
+    h = len(wg) // 2
+    print(f"  actor half: end median {np.median(en[:h]):.2f} max {en[:h].max():.2f};  critic half: end median {np.median(en[h:]):.2f} max {en[h:].max():.2f}")
+    order = np.argsort(en)[-8:]
+    print("  last to finish (wg: start, end):", [(int(i), round(float(st[i]), 2), round(float(en[i]), 2)) for i in order])
