@@ -256,12 +256,20 @@ __global__ void __launch_bounds__(64 * LG_TRAIN_WAVES * SLOTS) k_mlp_train(const
     float4 (*x)[64] = reinterpret_cast<float4 (*)[64]>(area + S::x);
     float (*xT)[16][LG_TT] = reinterpret_cast<float (*)[16][LG_TT]>(area + S::xT);
     float (*gT)[16][LG_TT] = reinterpret_cast<float (*)[16][LG_TT]>(area + S::gT);
+    // phase stamps of workgroup (0, 0), thread 0: -DLG_PROFILE builds only (tools/profile_sections.py build; TRACE=1 tools/mlp_probe.py)
+#ifdef LG_PROFILE
     unsigned long long *tr = (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ? A.trace : nullptr;
     int tri = 0;
 #define LG_TR() do { if (tr && tri < 60) tr[tri++] = __builtin_readcyclecounter(); } while (0)
-    // (diagnostic) every workgroup also leaves its start / end on the 100 MHz wall clock behind the 64 stamps: [64 + 2 * wg], [65 + 2 * wg]
+#else
+#define LG_TR() do { } while (0)
+#endif
+#ifdef LG_PROFILE
+    // (diagnostic build: these few registers cost the fused kernel 2.4 us) every workgroup also leaves its start / end on the 100 MHz wall clock
+    // behind the 64 stamps: [64 + 2 * wg], [65 + 2 * wg]; tools/mlp_probe.py prints the spread
     unsigned long long *wgclk = (A.trace && threadIdx.x == 0) ? A.trace + 64 + 2 * (blockIdx.y * gridDim.x + blockIdx.x) : nullptr;
     if (wgclk) wgclk[0] = wall_clock64();
+#endif
     LG_TR();
     const MlpNetArgs &N = A.net[blockIdx.y];
     // role of this wave within its group, rotated by the group index: the thin layers (2 and 1 output tiles) land on different SIMDs
@@ -481,7 +489,9 @@ __global__ void __launch_bounds__(64 * LG_TRAIN_WAVES * SLOTS) k_mlp_train(const
         case 2: row_tiles(std::integral_constant<int, 2>{}); break;
         default: row_tiles(std::integral_constant<int, 3>{}); break;
     }
-    if (tr) { tr[61] = wgclk[0]; tr[62] = wall_clock64(); }      // (diagnostic) wall clock at the start and at the end of the row-tile loop
+#ifdef LG_PROFILE
+    if (tr) { tr[61] = wgclk[0]; tr[62] = wall_clock64(); }      // wall clock at the start and at the end of the row-tile loop
+#endif
     // The groups of a workgroup fold their accumulators through LDS (the activation areas are free now) in group order, so each
     // workgroup writes ONE partial: half the workspace traffic and half the work of k_mlp_reduce with 2 groups.
     if (BWD) {
@@ -545,8 +555,10 @@ __global__ void __launch_bounds__(64 * LG_TRAIN_WAVES * SLOTS) k_mlp_train(const
         train_flush<D3T, 1>(a3, part, d3, d4, wave, lane);
     }
     LG_TR();
+#ifdef LG_PROFILE
     if (wgclk) wgclk[1] = wall_clock64();
     if (tr) tr[63] = wgclk[1];
+#endif
 #undef LG_TR
 }
 

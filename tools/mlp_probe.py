@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Times the learner kernels (lg_mlp_forward / lg_mlp_backward) against torch autograd on the flat actor+critic shapes."""
+"""TRACE=1 needs the -DLG_PROFILE build: python tools/profile_sections.py build, then LG_HIP_LIB=<csrc>/liblegged_hip_prof.so.
+Times the learner kernels (lg_mlp_forward / lg_mlp_backward) against torch autograd on the flat actor+critic shapes."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.realpath(__file__))))
 import torch, torch.nn as nn
@@ -61,6 +62,8 @@ if os.environ.get("TRACE"):
     raw = buf.cpu().tolist()
     t = [v for v in raw[:60] if v]
     print("ppo_minibatch stamps:", len(t), "deltas:", [t[i + 1] - t[i] for i in range(len(t) - 1)], "total", t[-1] - t[0])
+    if not any(raw[64:]):
+        print("(per-workgroup clocks: -DLG_PROFILE build only)"); sys.exit(0)
     print(f"workgroup (0,0) on the wall clock: row-tile loop ends {(raw[62] - raw[61]) / 100.0:.2f} us after its start, kernel body ends at {(raw[63] - raw[61]) / 100.0:.2f} us")
     import numpy as np
     wg = np.array(raw[64:], dtype=np.int64).reshape(-1, 2)
