@@ -118,12 +118,13 @@ def workload_text(task, env, pol, num_envs):
             "fixed command (0.5,0,0), obs noise + friction/mass randomisation + pushes on")
 
 
-def _update_path(alg):
+def _update_path(alg, world=1):
     tr = getattr(alg, "_mlp", None)
     if tr is None:
         return "torch autograd"
     if getattr(tr, "has_fused_minibatch", False):
-        return "lg_ppo_minibatch: forward + PPO loss + backward in one f32-MFMA kernel (v_mfma_f32_16x16x4_f32), lg_adam_step; one HIP graph per update"
+        return ("lg_ppo_minibatch: forward + PPO loss + backward in one f32-MFMA kernel (v_mfma_f32_16x16x4_f32), lg_adam_step; "
+                + ("one HIP graph per update" if world == 1 else "eager launches with one flat all-reduce between the backward and the optimiser step"))
     return ("wide learner kernels: chain forward k_mlp_chain_fwd64 + tiled dX / dW GEMMs (ds_read_b64_tr_b16 operand staging), split-bf16 products (hi*hi + hi*lo + lo*hi, f32 accumulate) "
             "on v_mfma_f32_32x32x16_bf16 (lg_mlp_wide_set_precision(1), the default; 0 = f32 MFMA), lg_ppo_loss, lg_adam_step")
 
@@ -438,7 +439,7 @@ def training_leg(a, iters, rank, local_rank, world, coll_dev, ranks_seen, backen
     alg = runner.alg
     out = {"value": world * a.num_envs * T * iters / dt, "unit": "env-steps/s (rollout + PPO update, whole job)", "iterations": iters,
            "ms_per_iteration": 1e3 * dt / iters, "steps_per_env": T, "epochs_x_minibatches": [alg.num_learning_epochs, alg.num_mini_batches],
-           "update_path": _update_path(alg),
+           "update_path": _update_path(alg, world),
            "final_learning_rate": float(alg.learning_rate),
            "note": "includes re-capturing the rollout graph at the start of the timed learn() call"}
     if world > 1:
