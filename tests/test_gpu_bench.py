@@ -62,3 +62,24 @@ def test_a_failing_ppo_leg_at_world_2_leaves_the_headline_line(fault):
                env={"LG_BENCH_BACKEND": "gloo", "LG_BENCH_PPO_FAULT": fault, "LG_BENCH_PPO_TIMEOUT_S": "20"})
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["gloo_ranks"] == 2
     assert "error" in out["ppo_training"]
+
+
+def test_bench_under_the_drivers_launcher():
+    """The driver starts N > 1 as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
+    bench.py --gpus N ...`: bench.py must take rank / world from the env (not spawn again) and rank 0 alone prints the line."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    e = dict(os.environ, LG_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        e.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "20", "--num-envs", "512", "--no-cpu-baseline", "--training-iters", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=e, cwd=REPO)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["gloo_ranks"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["ppo_training"]["collectives_per_iteration"]["ranks"] == 2 and "eager launches" in out["ppo_training"]["update_path"]
