@@ -99,7 +99,7 @@ __device__ __forceinline__ void lg_prof(int idx, unsigned long long *out, unsign
     unsigned long long t = __builtin_readcyclecounter();
     if (threadIdx.x == 0) {
         if (idx < 0) { for (int i = 0; i < LG_NPROF; i++) acc[i] = 0; t0 = t; w0 = wall_clock64(); }
-        else if (idx >= 18) { acc[idx] = note; t = prev; }           // user slots 18, 19: a value, not a time; the clock is not advanced
+        else if (idx >= 18) { if (idx == 18) acc[18] = note; else acc[19] += note; t = prev; }   // user slots: 18 a value, 19 a sum of packed event counts (LG_PROF_COUNT); the clock is not advanced
         else acc[idx] += t - prev;
         if (out) {
             acc[14] = t - t0; acc[15] = wall_clock64() - w0;
@@ -120,11 +120,14 @@ __device__ __forceinline__ void lg_prof(int idx, unsigned long long *out, unsign
 #define LG_PROF_BEGIN() lg_prof(-1, nullptr)
 #define LG_PROF_END(i, out) lg_prof(i, out)
 #define LG_PROF_NOTE(i, v) lg_prof(i, nullptr, v)
+// rare-path census of the rigid-body wave (converged code only): field f of slot 19 counts the times ANY lane took the path, field 6 (16 bit) the lanes
+#define LG_PROF_COUNT(f, cond) do { const unsigned long long b_ = __ballot(cond); if (b_) lg_prof(19, nullptr, (1ull << (8 * (f))) + ((f) == 0 ? (unsigned long long)__popcll(b_) << 48 : 0ull)); } while (0)
 #else
 #define LG_PROF(i)
 #define LG_PROF_BEGIN()
 #define LG_PROF_END(i, out)
 #define LG_PROF_NOTE(i, v)
+#define LG_PROF_COUNT(f, cond)
 #endif
 enum { PF_PROLOGUE = 0, PF_TORQUE, PF_KINEMATICS, PF_INWARD, PF_BASE, PF_OUTWARD, PF_INTEGRATE, PF_POST, PF_EXTRAS,
        PF_POST_HEIGHTS, PF_POST_TERMS, PF_POST_REWARD, PF_POST_RESET, PF_POST_OBS };
@@ -675,13 +678,15 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, int lane_k, float 
             const float *tj = tab + j * LG_JS;
             AI IA = I0[j]; S6 pA = p0[j];
 #pragma unroll
-            for (int i = 0; i < NPT; i++) if (T::pt_joint(i) == j) contact_assemble(cl[i], P, kn, IA, pA);
+            for (int i = 0; i < NPT; i++) if (T::pt_joint(i) == j) { LG_PROF_COUNT(0, cl[i].on); contact_assemble(cl[i], P, kn, IA, pA); }
             if (j < L - 1) { ai_add(IA, Ia); pA = pA + pa; }
             U[j] = ai_mul_w(IA, ax[j]);
             float damp = tj[J_DAMP];
             float D = dot(ax[j], U[j].w) + tj[J_ARM] + dt * damp;
             float u = motor_torque(tau[j], qd[j], tj[J_VLIM]) - dot(ax[j], pA.w) - damp * qd[j];
             float lo = tj[J_LO], hi = tj[J_HI];
+            LG_PROF_COUNT(3, lo <= hi && (q[j] + dt * qd[j] < lo || q[j] + dt * qd[j] > hi));
+            LG_PROF_COUNT(4, vl[j] != 0.0f);
             if (lo <= hi) {
                 float qp = q[j] + dt * qd[j];
                 bool blo = qp < lo, bhi = qp > hi;
@@ -704,6 +709,8 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, int lane_k, float 
             ai_shift(Ia, pa, db[j]);                 // to the parent's origin (the base origin for j == 0)
         }
         LG_PROF(PF_INWARD);
+        LG_PROF_COUNT(1, cb.on);
+        LG_PROF_COUNT(2, any_self);
         contact_assemble(cb, P, kn, Ia, pa);      // this lane's base point (about the base origin, like Ia after the shift)
         if (SC && any_self) {                     // (final pass only) reactions of this limb's base contacts: force -n f0 on the base, implicit in the base's motion
             const int ln = threadIdx.x % LG_BLOCK;
