@@ -91,12 +91,18 @@ print(f"  resets in the launch: {int(nr.sum())} envs in {int((nr > 0).sum())} wo
 cnt = B[:, 19].astype(np.uint64)
 F = {"limb contact branches": (cnt & np.uint64(0xFF)), "base contact branch": ((cnt >> np.uint64(8)) & np.uint64(0xFF)), "self-collision passes": ((cnt >> np.uint64(16)) & np.uint64(0xFF)),
      "joint-limit branches": ((cnt >> np.uint64(24)) & np.uint64(0xFF)), "speed-limit branches": ((cnt >> np.uint64(32)) & np.uint64(0xFF)), "limb contact lanes": ((cnt >> np.uint64(48)) & np.uint64(0xFFFF))}
-X = np.stack([f.astype(np.float64) for f in F.values()] + [nr, np.ones(nb)], axis=1)
+cols = [(name, np.asarray(f, dtype=np.float64)) for name, f in list(F.items()) + [("reset envs", nr)]]
+var = [(name, f) for name, f in cols if f.max() > f.min()]            # a count that is the same in every workgroup is part of the intercept
+X = np.stack([f for _, f in var] + [np.ones(nb)], axis=1)
 coef, *_ = np.linalg.lstsq(X, B[:, 14] / ghz / 1e3, rcond=None)
+cost = dict(zip([name for name, _ in var], coef[:-1]))
 print("  rare-path census per workgroup (count: median / p90 / max; least-squares cost per event in us; mean contribution in us):")
-for (name, f), c in zip(list(F.items()) + [("reset envs", nr)], coef[:-1]):
-    f = np.asarray(f, dtype=np.float64)
-    print(f"    {name:24s} {np.median(f):6.0f} / {np.quantile(f, 0.9):6.0f} / {f.max():6.0f}   {c:+8.3f} us each   {c * f.mean():+7.2f} us mean   {c * (f.max() - np.median(f)):+7.2f} us max - median")
+for name, f in cols:
+    if name in cost:
+        c = cost[name]
+        print(f"    {name:24s} {np.median(f):6.0f} / {np.quantile(f, 0.9):6.0f} / {f.max():6.0f}   {c:+8.3f} us each   {c * f.mean():+7.2f} us mean   {c * (f.max() - np.median(f)):+7.2f} us max - median")
+    else:
+        print(f"    {name:24s} {np.median(f):6.0f} / {np.quantile(f, 0.9):6.0f} / {f.max():6.0f}   the same in every workgroup (part of the intercept)")
 res = B[:, 14] / ghz / 1e3 - X @ coef
 print(f"    intercept {coef[-1]:.1f} us; residual std {res.std():.2f} us (total std {(B[:, 14] / ghz / 1e3).std():.2f})")
 print("  XCD (blockIdx % 8) mean total us:", [round(B[np.arange(nb) % 8 == x, 14].mean() / ghz / 1e3, 1) for x in range(8)])
