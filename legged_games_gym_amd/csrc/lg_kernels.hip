@@ -116,12 +116,20 @@ __device__ __forceinline__ void lg_prof(int idx, unsigned long long *out, unsign
     }
     __builtin_amdgcn_sched_barrier(0);
 }
+#ifdef LG_PROFILE_LIGHT       // only each workgroup's start / end on the wall clock: the spread of the PRODUCT kernel's workgroups (no section stamps, no census)
+#define LG_PROF(i)
+#else
 #define LG_PROF(i) lg_prof(i, nullptr)
+#endif
+#define LG_PROF_NOTE(i, v) lg_prof(i, nullptr, v)
 #define LG_PROF_BEGIN() lg_prof(-1, nullptr)
 #define LG_PROF_END(i, out) lg_prof(i, out)
-#define LG_PROF_NOTE(i, v) lg_prof(i, nullptr, v)
 // rare-path census of the rigid-body wave (converged code only): field f of slot 19 counts the times ANY lane took the path, field 6 (16 bit) the lanes
+#ifdef LG_PROFILE_LIGHT      // the two events of a fallen robot only: trunk contact (1) and self-collision (2) passes
+#define LG_PROF_COUNT(f, cond) do { if ((f) == 1 || (f) == 2) { if (__ballot(cond)) lg_prof(19, nullptr, 1ull << (8 * (f))); } } while (0)
+#else
 #define LG_PROF_COUNT(f, cond) do { const unsigned long long b_ = __ballot(cond); if (b_) lg_prof(19, nullptr, (1ull << (8 * (f))) + ((f) == 0 ? (unsigned long long)__popcll(b_) << 48 : 0ull)); } while (0)
+#endif
 #else
 #define LG_PROF(i)
 #define LG_PROF_BEGIN()
@@ -1111,7 +1119,7 @@ template <class T> LG_DEV void stage_limb_table(const KArgs &A, float *lds_tab) 
 }
 
 // ------------------------------------------------------------------ extras["episode"] finisher (legged_robot.py:179-188)
-LG_DEV void finish_extras(const KArgs &A, int t, int64_t step_used, bool publish_step) {
+LG_DEV void finish_extras(const KArgs &A, int t, int64_t step_used, bool publish_step, bool level_parts = false) {
     const lg_params &P = A.P;
     const int R = P.num_reward_slots;
     __shared__ float level_part[16];
@@ -1126,12 +1134,18 @@ LG_DEV void finish_extras(const KArgs &A, int t, int64_t step_used, bool publish
         float acc = 0.0f;
         const int nt = blockDim.x;
         constexpr int INFLIGHT = 8;                                // (32 in flight measured no faster)
-        for (int e0 = t; e0 < P.num_envs; e0 += nt * INFLIGHT) {
+        // k_step with helper waves: every workgroup left the sum of its own envs' levels behind its ticket (HelperWave, after P3), so the
+        // last one adds gridDim.x numbers -- one round trip past the caches instead of num_envs / (8 x threads) of them (2 at 4096 envs,
+        // 4 at 8192: the light profile showed this workgroup ending 5 / 9 us after every other one)
+        const int *parts = reinterpret_cast<const int *>(A.done_counter + 1);
+        const int n_items = level_parts ? (int)gridDim.x : P.num_envs;
+        const int *items = level_parts ? parts : A.B.terrain_levels;
+        for (int e0 = t; e0 < n_items; e0 += nt * INFLIGHT) {
             int lv[INFLIGHT];
 #pragma unroll
             for (int u = 0; u < INFLIGHT; u++) {
                 const int e = e0 + u * nt;
-                lv[u] = e < P.num_envs ? __hip_atomic_load(A.B.terrain_levels + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+                lv[u] = e < n_items ? __hip_atomic_load(items + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
             }
 #pragma unroll
             for (int u = 0; u < INFLIGHT; u++) acc += (float)lv[u];
@@ -1325,6 +1339,13 @@ template <class T, bool NET, bool HF, int NW, bool SC = false> struct HelperWave
         __syncthreads();                                           // P3: reset flags / post-reset root z / reward terms published
         if (wave == 1) {
             es.template update<T::K>(A, e, lane, sh, keeper);
+            if (P.terrain_curriculum && A.B.terrain_levels) {      // (wave-uniform) this workgroup's share of the mean terrain level: the reset
+                // lanes' new levels were stored and drained by the rigid-body wave before P3; read past this CU's L1, which may hold the old line
+                int lv = keeper ? __hip_atomic_load(A.B.terrain_levels + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) lv += __shfl_xor(lv, o);
+                if (lane == 0) __hip_atomic_store(reinterpret_cast<int *>(A.done_counter + 1) + blockIdx.x, lv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             // Workgroup ticket for the extras finisher, taken HERE: what the last workgroup's finisher reads are the episode-sum
             // atomics just issued by this wave (and terrain levels, drained by the rigid-body wave before P3), so the ticket only
             // has to follow their completion -- both round trips (drain, ticket) overlap the rigid-body wave's observations and
@@ -1680,7 +1701,7 @@ __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
         }
     }
     __syncthreads();                                               // s_last published (NW > 1: helper wave 1 took the ticket after P3)
-    if (s_last) finish_extras(A, threadIdx.x, step, true);
+    if (s_last) finish_extras(A, threadIdx.x, step, true, NW > 1);
     LG_PROF_END(PF_EXTRAS, A.prof);
 }
 
@@ -2811,7 +2832,10 @@ int lg_create(const lg_params *params, const lg_robot_model *model, const float 
     if (!s) return fail(-5, "out of host memory");
     s->P = *params; s->M = *model; s->kind = kind; s->device = device_id; s->bound = false;
     s->has_net = actuator_weights != nullptr; s->d_weights = nullptr; s->d_limb_table = nullptr; s->d_done = nullptr; s->d_prof = nullptr;
-    if (hipMalloc(&s->d_done, sizeof(unsigned int)) != hipSuccess || hipMemset(s->d_done, 0, sizeof(unsigned int)) != hipSuccess) { delete s; return fail(-10, "hipMalloc failed"); }
+    {   // [0] the workgroup ticket, [1 ..] one terrain-level partial sum per workgroup of k_step (at most 4 lanes per env)
+        const size_t n_done = 1 + ((size_t)params->num_envs * 4 + LG_BLOCK - 1) / LG_BLOCK;
+        if (hipMalloc(&s->d_done, n_done * sizeof(unsigned int)) != hipSuccess || hipMemset(s->d_done, 0, n_done * sizeof(unsigned int)) != hipSuccess) { delete s; return fail(-10, "hipMalloc failed"); }
+    }
     memset(&s->B, 0, sizeof s->B);
     { hipDeviceProp_t prop; s->num_cus = (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256; }
 #ifdef LG_PROFILE

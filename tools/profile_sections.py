@@ -4,6 +4,7 @@ every workgroup), runs the bench workload for a few hundred steps and prints the
 
   python tools/profile_sections.py build            # here (hipcc cross-compiles) -> csrc/liblegged_hip_prof.so
   python tools/profile_sections.py run [task] [N]   # on the GPU box
+  ... build light / run [task] [N] light            # -DLG_PROFILE_LIGHT: only each workgroup's start / end clock (spread of the product kernel)
 """
 import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.realpath(__file__)))
@@ -14,9 +15,12 @@ NAMES = ["prologue (tables, state loads)", "torques (actuator LSTM / PD)", "kine
          "base: butterfly + 6x6 solve", "outward accelerations + contact evaluate", "integrate + force sums", "post-physics (rewards, reset, obs)", "extras finisher",
          "post: commands, heights, push, contact force export", "post: termination + reward terms", "post: reward sum + episode sums", "post: reset block", "post: observations"]
 
+LIGHT = "light" in sys.argv          # -DLG_PROFILE_LIGHT: start / end of every workgroup only (the product kernel's own spread)
+if LIGHT:
+    LIB = os.path.join(CSRC, "liblegged_hip_prof_light.so")
 if sys.argv[1:2] == ["build"]:
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-fno-slp-vectorize",
-           "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-mllvm", "-amdgpu-mfma-vgpr-form", "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0", "-DLG_PROFILE", "-o", LIB, os.path.join(CSRC, "lg_kernels.hip")]
+           "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-mllvm", "-amdgpu-mfma-vgpr-form", "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0", "-DLG_PROFILE"] + (["-DLG_PROFILE_LIGHT"] if LIGHT else []) + ["-o", LIB, os.path.join(CSRC, "lg_kernels.hip")]
     print(" ".join(cmd)); subprocess.run(cmd, check=True); sys.exit(0)
 
 os.environ["LG_HIP_LIB"] = LIB
@@ -64,7 +68,7 @@ v = [int(x) for x in out]
 wgs = steps * ((env.num_envs * (2 if task == "cassie" else 4) + 63) // 64)
 tot, wall = v[14] / wgs, v[15] / wgs * 10.0          # cycles per workgroup-step; ns (100 MHz wall clock)
 print(f"{task} N={env.num_envs}: {t0.elapsed_time(t1) / steps * 1e3:.1f} us per env.step (instrumented build); per workgroup {tot:.0f} cycles = {wall / 1e3:.1f} us -> {tot / wall:.2f} GHz counter")
-for i, name in enumerate(NAMES):
+for i, name in enumerate([] if LIGHT else NAMES):
     c = v[i] / wgs
     print(f"  {name:45s} {c:9.0f} cyc  {c / tot * 100:5.1f} %  {c / tot * wall / 1e3:6.2f} us")
 print(f"  slowest workgroup of any launch: {v[16]} cycles = {v[16] / (tot / wall) / 1e3:.1f} us (the kernel ends when it does)")
@@ -81,6 +85,19 @@ ghz = tot / wall
 print(f"last launch, {nb} workgroups: total per workgroup min {B[:, 14].min() / ghz / 1e3:.1f}  median {np.median(B[:, 14]) / ghz / 1e3:.1f}  p90 {np.quantile(B[:, 14], 0.9) / ghz / 1e3:.1f}  max {B[:, 14].max() / ghz / 1e3:.1f} us")
 start = (B[:, 16] - B[:, 16].min()) * 10.0 / 1e3; end = (B[:, 17] - B[:, 16].min()) * 10.0 / 1e3
 print(f"  start skew: median {np.median(start):.2f} max {start.max():.2f} us;  last end {end.max():.1f} us;  median end {np.median(end):.1f} us")
+if LIGHT:
+    dur = end - start
+    print(f"  own duration (wall clock): min {dur.min():.1f}  p10 {np.quantile(dur, 0.1):.1f}  median {np.median(dur):.1f}  p90 {np.quantile(dur, 0.9):.1f}  p99 {np.quantile(dur, 0.99):.1f}  max {dur.max():.1f} us")
+    print(f"  end of workgroup: p10 {np.quantile(end, 0.1):.1f}  median {np.median(end):.1f}  p90 {np.quantile(end, 0.9):.1f}  p99 {np.quantile(end, 0.99):.1f}  last {end.max():.1f} us")
+    print("  XCD (blockIdx % 8) mean end us:", [round(float(end[np.arange(nb) % 8 == x].mean()), 1) for x in range(8)])
+    cnt = B[:, 19].astype(np.uint64); nrs = B[:, 18]
+    basep, scp = ((cnt >> np.uint64(8)) & np.uint64(0xFF)).astype(int), ((cnt >> np.uint64(16)) & np.uint64(0xFF)).astype(int)
+    calm = (nrs == 0) & (basep == 0) & (scp == 0)
+    print(f"  workgroups without a reset, a trunk contact or a self-collision pass: {int(calm.sum())} of {nb}, own duration median {np.median(dur[calm]):.1f} max {dur[calm].max():.1f} us;"
+          f"  the others: median {np.median(dur[~calm]) if (~calm).any() else 0:.1f} max {dur[~calm].max() if (~calm).any() else 0:.1f} us")
+    print("  slowest workgroups (blockIdx: own us | resets, trunk-contact passes, self-collision passes):",
+          [(int(b), round(float(dur[b]), 1), int(nrs[b]), int(basep[b]), int(scp[b])) for b in np.argsort(dur)[-10:]])
+    sys.exit(0)
 slow = np.argsort(B[:, 14])[-max(1, nb // 20):]
 for i, name in enumerate(NAMES):
     print(f"  {name:45s} median {np.median(B[:, i]) / ghz / 1e3:6.2f}  p90 {np.quantile(B[:, i], 0.9) / ghz / 1e3:6.2f}  max {B[:, i].max() / ghz / 1e3:6.2f}  | slowest 5% of workgroups: {B[slow, i].mean() / ghz / 1e3:6.2f} us")
