@@ -30,6 +30,13 @@ with open(os.path.join(DST, "r02_sections.txt"), "w") as f:
         txt = open(os.path.join(SRC, f"sections_{task}.txt")).read()
         i = txt.find(task + " N=")
         f.write("\n" + re.sub(r"np\.float64\(([^)]*)\)", r"\1", txt[i:] if i >= 0 else txt))
+    f.write("\n# ---- the LIGHT build (-DLG_PROFILE_LIGHT: each workgroup's start / end clock and the fallen-robot events only): the spread of the PRODUCT kernel's workgroups\n")
+    for task in ("anymal_c_flat", "anymal_c_rough", "cassie"):
+        path = os.path.join(SRC, f"light_{task}.txt")
+        if os.path.exists(path):
+            txt = open(path).read()
+            i = txt.find(task + " N=")
+            f.write("\n" + re.sub(r"np\.float64\(([^)]*)\)", r"\1", txt[i:] if i >= 0 else txt))
 
 with open(os.path.join(DST, "r02_training.txt"), "w") as f:
     f.write("# tools/train_probe.py <iterations> <task>: bundled PPO runner, 4096 envs, registered configs (rough tasks: 'trimesh' faces, terrain curriculum)\n")

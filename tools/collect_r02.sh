@@ -22,6 +22,7 @@ echo "[section profiles]"
 for t in "anymal_c_flat 4096" "anymal_c_rough 4096" "cassie 8192"; do
     set -- $t
     timeout -k 10 200 python3 tools/profile_sections.py run $1 $2 > "$OUT/sections_$1.txt" 2>&1 || exit 1
+    timeout -k 10 200 python3 tools/profile_sections.py run $1 $2 light > "$OUT/light_$1.txt" 2>&1 || exit 1      # needs `build light` too
 done
 echo "[training curves]"
 for t in "anymal_c_flat 300" "anymal_c_rough 300" "cassie 300"; do
