@@ -2,6 +2,8 @@
 # Round-2 evidence beyond tools/collect_profiles.sh (run through gpurun from the repo root; outputs under gpurun_out/r02/):
 #   bench lines + rocprofv3 kernel tables of BASELINE configs 3 and 5, the wide learner's per-launch timeline, per-workgroup
 #   section profiles of k_step, training curves.  tools/collect_r02.py copies the summaries into profiles/.
+# Before the gpurun call, HERE: python tools/profile_sections.py build && python tools/profile_sections.py build light  (the two -DLG_PROFILE libraries
+# travel with the snapshot; a stale one profiles the OLD kernel source).
 set -o pipefail
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/r02
