@@ -175,6 +175,16 @@ int  lg_bind(lg_sim *sim, const lg_buffers *buffers);
  * Asynchronous on `stream`. */
 int  lg_step(lg_sim *sim, const float *actions, int64_t common_step_counter, void *stream);
 
+/* Deferred extras (rollout graphs).  lg_step turns the finished episodes' sums into extras["episode"] (`episode_means`,
+ * legged_robot.py:179-186) before it returns, which costs every launch a serial tail: the workgroup that finishes last
+ * reads the accumulators past the caches.  With lg_set_deferred_extras(sim, 1) a step leaves its sums in one of two
+ * accumulator slots (step parity) and the NEXT step's launch publishes them while it runs; lg_extras_flush publishes what the
+ * last step left (pass the same common_step_counter convention as lg_step: the last step's value, or -1 = device counter).
+ * Callers that read extras after every step (the eager env.step) keep the default (0); a captured rollout graph switches
+ * it on for its steps and ends with one lg_extras_flush node. */
+int  lg_set_deferred_extras(lg_sim *sim, int32_t on);
+int  lg_extras_flush(lg_sim *sim, int64_t common_step_counter, void *stream);
+
 /* reset_idx on an explicit env list (base_task.py:114-118 reset(); device int32 ids). */
 int  lg_reset_idx(lg_sim *sim, const int32_t *env_ids, int32_t count,
                   int64_t common_step_counter, void *stream);

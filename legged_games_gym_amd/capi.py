@@ -271,6 +271,8 @@ def bind_prototypes(lib, prefix: str):
         lib.lg_rollout_record.argtypes = [C.POINTER(lg_rollout_step), vp]
         lib.lg_rollout_record.restype = C.c_int
         lib.lg_mlp_trace.argtypes, lib.lg_mlp_trace.restype = [vp], None
+        lib.lg_set_deferred_extras.argtypes, lib.lg_set_deferred_extras.restype = [vp, i32], C.c_int
+        lib.lg_extras_flush.argtypes, lib.lg_extras_flush.restype = [vp, i64, vp], C.c_int
     for name, (args, res) in sig.items():
         fn = getattr(lib, prefix + name)
         fn.argtypes, fn.restype = args, res
@@ -286,7 +288,7 @@ EXPORTED_SYMBOLS = ["lg_create", "lg_destroy", "lg_bind", "lg_step", "lg_reset_i
                     "lg_physics_substep", "lg_compute_observations_only", "lg_set_params", "lg_last_error",
                     "lg_abi_version", "lg_sizeof", "lg_set_obs_buffer", "lg_policy_create", "lg_policy_destroy", "lg_policy_act",
                     "lg_step_policy", "lg_gae_returns", "lg_ppo_loss", "lg_policy_load_device", "lg_mlp_forward",
-                    "lg_mlp_workspace_bytes", "lg_mlp_backward", "lg_mlp_wide_workspace_bytes", "lg_mlp_wide_forward", "lg_mlp_wide_backward", "lg_mlp_wide_set_precision", "lg_adam_step", "lg_rollout_record", "lg_mlp_trace", "lg_ppo_minibatch"]
+                    "lg_mlp_workspace_bytes", "lg_mlp_backward", "lg_mlp_wide_workspace_bytes", "lg_mlp_wide_forward", "lg_mlp_wide_backward", "lg_mlp_wide_set_precision", "lg_adam_step", "lg_rollout_record", "lg_mlp_trace", "lg_ppo_minibatch", "lg_set_deferred_extras", "lg_extras_flush"]
 
 
 def load_library():
@@ -345,6 +347,12 @@ class Sim:
                     common_step_counter: int, stream: int = 0):
         self._check(self.lib.lg_step_policy(self.handle, policy_handle, obs_ptr, actions_ptr, mean_ptr, int(seed), int(bool(deterministic)),
                                             int(common_step_counter), stream))
+
+    def set_deferred_extras(self, on: bool):
+        self._check(self.lib.lg_set_deferred_extras(self.handle, int(bool(on))))
+
+    def extras_flush(self, common_step_counter: int, stream: int = 0):
+        self._check(self.lib.lg_extras_flush(self.handle, int(common_step_counter), stream))
 
     def reset_idx(self, ids_ptr: int, count: int, common_step_counter: int, stream: int = 0):
         self._check(self._fn("reset_idx")(self.handle, ids_ptr, int(count), int(common_step_counter), stream))

@@ -80,7 +80,10 @@ struct KArgs {                 // passed by value: lives in the kernarg segment 
     const int32_t *env_ids;    // reset kernel only
     int32_t    count;
     uint32_t   penalised_mask, termination_mask;
-    unsigned int *done_counter;   // workgroup ticket of k_step (zeroed at create, self-resetting)
+    unsigned int *done_counter;   // workgroup ticket of k_step (zeroed at create, self-resetting); behind it 2 x gridDim.x terrain-level partial sums
+    float *accum_alt;             // deferred extras (lg_set_deferred_extras): the episode accumulators of ODD steps (even ones use B.extras_accum)
+    int   flush_parts;            // k_extras as lg_extras_flush: number of level partial sums to add (0: scan terrain_levels)
+    int   defer;                  // 1: no finisher in this launch -- workgroup 0 turns the PREVIOUS step's accumulators into episode_means instead
     int64_t    step;
     PolicyArgs pol;               // fused rollout step (k_step<..., POL = true>): the actor that produces this step's actions
     unsigned long long *prof;     // LG_PROFILE builds only: [LG_NPROF] cycle accumulators (tools/profile_sections.py)
@@ -1119,15 +1122,19 @@ template <class T> LG_DEV void stage_limb_table(const KArgs &A, float *lds_tab) 
 }
 
 // ------------------------------------------------------------------ extras["episode"] finisher (legged_robot.py:179-188)
-LG_DEV void finish_extras(const KArgs &A, int t, int64_t step_used, bool publish_step, bool level_parts = false) {
+// Deferred extras: with A.defer the episode accumulators and the level partial sums alternate between two slots by
+// step parity; launch s fills slot s & 1 while its workgroup 0 finishes slot (s - 1) & 1, which the previous launch completed.
+LG_DEV float *accum_slot(const KArgs &A, int64_t step) { return (A.defer && (step & 1)) ? A.accum_alt : A.B.extras_accum; }
+LG_DEV int *level_parts_slot(const KArgs &A, int64_t step, int nwg) { return reinterpret_cast<int *>(A.done_counter + 1) + ((step & 1) ? nwg : 0); }   // (always by parity: the slot of step - 1 is valid whatever mode wrote it)
+LG_DEV void finish_extras(const KArgs &A, int t, int64_t step_used, bool publish_step, float *accum, const int *parts = nullptr, int n_parts = 0, bool do_levels = true) {
     const lg_params &P = A.P;
     const int R = P.num_reward_slots;
     __shared__ float level_part[16];
     if (publish_step && t == 0 && A.B.step_counter) A.B.step_counter[0] = step_used;
     // accumulators were updated with device-scope atomics by other workgroups: read them past the L1 (sc1 loads)
-    float cnt = __hip_atomic_load(A.B.extras_accum + R, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    float v = (t < R) ? __hip_atomic_load(A.B.extras_accum + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
-    const bool levels = P.terrain_curriculum && A.B.terrain_levels;
+    float cnt = __hip_atomic_load(accum + R, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    float v = (t < R) ? __hip_atomic_load(accum + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
+    const bool levels = do_levels && P.terrain_curriculum && A.B.terrain_levels;
     if (levels) {
         // mean terrain level (legged_robot.py:185-186): every thread of the workgroup, eight independent L1-bypassing loads in flight
         // each -- the serial 64-lane scan this replaces took 15 us at 4096 envs, and the kernel ends with this workgroup
@@ -1137,9 +1144,8 @@ LG_DEV void finish_extras(const KArgs &A, int t, int64_t step_used, bool publish
         // k_step with helper waves: every workgroup left the sum of its own envs' levels behind its ticket (HelperWave, after P3), so the
         // last one adds gridDim.x numbers -- one round trip past the caches instead of num_envs / (8 x threads) of them (2 at 4096 envs,
         // 4 at 8192: the light profile showed this workgroup ending 5 / 9 us after every other one)
-        const int *parts = reinterpret_cast<const int *>(A.done_counter + 1);
-        const int n_items = level_parts ? (int)gridDim.x : P.num_envs;
-        const int *items = level_parts ? parts : A.B.terrain_levels;
+        const int n_items = parts ? n_parts : P.num_envs;
+        const int *items = parts ? parts : A.B.terrain_levels;
         for (int e0 = t; e0 < n_items; e0 += nt * INFLIGHT) {
             int lv[INFLIGHT];
 #pragma unroll
@@ -1158,9 +1164,9 @@ LG_DEV void finish_extras(const KArgs &A, int t, int64_t step_used, bool publish
     if (t >= 64) return;                            // blocks wider than one wave (k_step with actuator waves): wave 0 finishes
     if (t < R) {
         if (cnt > 0.0f) A.B.episode_means[t] = v / cnt / P.max_episode_length_s;
-        __hip_atomic_store(A.B.extras_accum + t, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(accum + t, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (t == R) __hip_atomic_store(A.B.extras_accum + R, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == R) __hip_atomic_store(accum + R, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (levels && t == 0) {
         float acc = 0.0f;
         for (int w = 0; w < (int)(blockDim.x >> 6); w++) acc += level_part[w];
@@ -1201,7 +1207,7 @@ struct EpisodeSums {
     // park their sums in sh.r_t (this wave has consumed it), lane t adds term t over the reset envs and issues the atomic for its
     // slot -- 18 single-lane atomics to one 128-byte line took ~3 us to drain (measured: workgroups with a reset env ended 3 us
     // later in the ticket section), and the kernel ends with its slowest workgroup.
-    template <int K, class SH> LG_DEV void update(const KArgs &A, int e, int lane, SH &sh, bool keep) {
+    template <int K, class SH> LG_DEV void update(const KArgs &A, int e, int lane, SH &sh, bool keep, float *accum) {
         const lg_params &P = A.P;
         const bool reset = keep && sh.rst[lane] != 0;
         if (keep) {
@@ -1226,8 +1232,8 @@ struct EpisodeSums {
             for (int t = 0; t < LG_NUM_REWARD_TERMS; t++) slot = lane == t ? P.reward_slot[t] : slot;
             float tot = 0.0f;
             for (int i = 0; i < LG_BLOCK; i += K) tot += sh.r_t[lane][i];
-            if (slot >= 0) atomicAdd(A.B.extras_accum + slot, tot);
-        } else if (lane == LG_NUM_REWARD_TERMS) atomicAdd(A.B.extras_accum + P.num_reward_slots, (float)__popcll(finished));
+            if (slot >= 0) atomicAdd(accum + slot, tot);
+        } else if (lane == LG_NUM_REWARD_TERMS) atomicAdd(accum + P.num_reward_slots, (float)__popcll(finished));
     }
 };
 
@@ -1338,24 +1344,34 @@ template <class T, bool NET, bool HF, int NW, bool SC = false> struct HelperWave
         if (P.measure_heights) hc.draw_noise(P, e, k + T::K * wave, step, un);
         __syncthreads();                                           // P3: reset flags / post-reset root z / reward terms published
         if (wave == 1) {
-            es.template update<T::K>(A, e, lane, sh, keeper);
+            es.template update<T::K>(A, e, lane, sh, keeper, accum_slot(A, step));
             if (P.terrain_curriculum && A.B.terrain_levels) {      // (wave-uniform) this workgroup's share of the mean terrain level: the reset
                 // lanes' new levels were stored and drained by the rigid-body wave before P3; read past this CU's L1, which may hold the old line
                 int lv = keeper ? __hip_atomic_load(A.B.terrain_levels + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) lv += __shfl_xor(lv, o);
-                if (lane == 0) __hip_atomic_store(reinterpret_cast<int *>(A.done_counter + 1) + blockIdx.x, lv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) __hip_atomic_store(level_parts_slot(A, step, gridDim.x) + blockIdx.x, lv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             // Workgroup ticket for the extras finisher, taken HERE: what the last workgroup's finisher reads are the episode-sum
             // atomics just issued by this wave (and terrain levels, drained by the rigid-body wave before P3), so the ticket only
             // has to follow their completion -- both round trips (drain, ticket) overlap the rigid-body wave's observations and
             // state write-back instead of standing at the end of the kernel.
+            if (A.defer) {
+                // deferred extras: the ticket's only job left is the device step counter -- whoever takes the LAST one knows that every workgroup
+                // has read the counter and may advance it.  Nothing to drain first, and no finisher behind it.  (Taken here and not in the
+                // prologue: an atomic with a return value in front of this wave's first loads delayed the first torques of every workgroup.)
+                if (lane == 0 && atomicAdd(A.done_counter, 1u) == gridDim.x - 1) {
+                    if (B.step_counter) B.step_counter[0] = step;
+                    __hip_atomic_store(A.done_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) {
                 const unsigned int ticket = atomicAdd(A.done_counter, 1u);
                 const int last = ticket == gridDim.x - 1;
                 if (last) __hip_atomic_store(A.done_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // idle until the next launch
                 *s_last = last;
+            }
             }
         }
         if (P.measure_heights) hc.write_obs(A, e, k + T::K * wave, live, step, sh.root_z[lane], un);
@@ -1640,7 +1656,7 @@ __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
     sh.rst[lane] = reset ? 1 : 0; sh.root_z[lane] = root[2];
     if (NW > 1 && P.terrain_curriculum) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // terrain_levels stores precede the ticket (helper wave 1, after P3)
     __syncthreads();                                               // P3: helpers write the height observations / actuator state
-    if (NW == 1) { EpisodeSums es; const bool keep = live && k == 0; if (keep) es.load(A, e); es.template update<K>(A, e, lane, sh, keep); }   // no helper wave: keep the sums here
+    if (NW == 1) { EpisodeSums es; const bool keep = live && k == 0; if (keep) es.load(A, e); es.template update<K>(A, e, lane, sh, keep, accum_slot(A, step)); }   // no helper wave: keep the sums here
 
     LG_PROF(PF_POST_RESET);
 #ifdef LG_PROFILE
@@ -1692,7 +1708,7 @@ __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
     // have drained (s_waitcnt vmcnt(0)), and the finisher reads with device-scope (L1-bypassing) loads.
     }   // physics wave
     LG_PROF(PF_POST);
-    if (NW == 1) {                                                 // no helper wave: ticket at the end, behind this wave's own memory operations
+    if (NW == 1 && !A.defer) {                                     // no helper wave: ticket at the end, behind this wave's own memory operations
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (threadIdx.x == 0) {
             unsigned int ticket = atomicAdd(A.done_counter, 1u);
@@ -1700,8 +1716,18 @@ __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
             if (s_last) __hip_atomic_store(A.done_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // idle until the next launch
         }
     }
+    if (A.defer) {                                                 // (kernel-uniform)
+        if (NW == 1 && threadIdx.x == 0 && atomicAdd(A.done_counter, 1u) == gridDim.x - 1) {      // (helper-wave kernels: HelperWave::run) every workgroup has read the step counter
+            if (B.step_counter) B.step_counter[0] = step;
+            __hip_atomic_store(A.done_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // the PREVIOUS step's accumulators (complete: that launch has ended) become episode_means here, next to 255 busy workgroups
+        if (blockIdx.x == 0) finish_extras(A, threadIdx.x, step, false, accum_slot(A, step - 1), NW > 1 ? level_parts_slot(A, step - 1, gridDim.x) : nullptr, gridDim.x);
+        LG_PROF_END(PF_EXTRAS, A.prof);
+        return;
+    }
     __syncthreads();                                               // s_last published (NW > 1: helper wave 1 took the ticket after P3)
-    if (s_last) finish_extras(A, threadIdx.x, step, true, NW > 1);
+    if (s_last) finish_extras(A, threadIdx.x, step, true, A.B.extras_accum, NW > 1 ? level_parts_slot(A, step, gridDim.x) : nullptr, gridDim.x);
     LG_PROF_END(PF_EXTRAS, A.prof);
 }
 
@@ -1771,7 +1797,10 @@ __global__ void __launch_bounds__(LG_BLOCK) k_reset(const KArgs A) {
 // means the reference logs (kept stale when nothing reset, quirk Q4), re-zeroes the accumulator, and refreshes the
 // mean terrain level.  Keeps env.step() free of per-step torch kernels and host syncs.
 __global__ void __launch_bounds__(64) k_extras(const KArgs A) {        // behind k_reset (and available stand-alone)
-    finish_extras(A, threadIdx.x, A.step, false);
+    // lg_extras_flush: whichever slot the last deferred step filled (the other one is empty); the level partial sums of that step if there are any
+    const int64_t last = A.step >= 0 ? A.step : (A.B.step_counter ? A.B.step_counter[0] : 0);
+    finish_extras(A, threadIdx.x, A.step, false, A.B.extras_accum, A.flush_parts > 0 ? level_parts_slot(A, last, A.flush_parts) : nullptr, A.flush_parts);
+    if (A.accum_alt) finish_extras(A, threadIdx.x, A.step, false, A.accum_alt, nullptr, 0, false);
 }
 
 // ------------------------------------------------------------------ sub-path kernels (parity tests drive these)
@@ -1897,6 +1926,8 @@ struct lg_sim {
     float         *d_limb_table;
     float         *d_weights;
     unsigned int  *d_done;
+    float         *d_accum_alt;      // deferred extras: accumulators of odd steps
+    int            defer;            // lg_set_deferred_extras
     unsigned long long *d_prof;
     int            num_cus;
 };
@@ -2060,6 +2091,7 @@ static void fill_args(const lg_sim *s, KArgs &a, int64_t step) {
     a.P = s->P; a.B = s->B; a.base = s->base; a.limb_table = s->d_limb_table; a.hpts = s->d_limb_table + LG_MAX_LIMBS * (LG_MAX_CHAIN * LG_JS + 4 * LG_MAX_LIMB_POINTS + 1); a.weights = s->d_weights;
     a.actions_in = nullptr; a.env_ids = nullptr; a.count = 0; a.step = step; memset(&a.pol, 0, sizeof a.pol);
     a.penalised_mask = s->M.penalised_mask; a.termination_mask = s->M.termination_mask; a.done_counter = s->d_done; a.prof = s->d_prof;
+    a.accum_alt = s->d_accum_alt; a.defer = s->defer; a.flush_parts = 0;
 }
 template <class T> static int grid_for(int n_env_like) { return (n_env_like * T::K + LG_BLOCK - 1) / LG_BLOCK; }
 
@@ -2831,9 +2863,10 @@ int lg_create(const lg_params *params, const lg_robot_model *model, const float 
     lg_sim *s = new (std::nothrow) lg_sim();
     if (!s) return fail(-5, "out of host memory");
     s->P = *params; s->M = *model; s->kind = kind; s->device = device_id; s->bound = false;
-    s->has_net = actuator_weights != nullptr; s->d_weights = nullptr; s->d_limb_table = nullptr; s->d_done = nullptr; s->d_prof = nullptr;
+    s->has_net = actuator_weights != nullptr; s->d_weights = nullptr; s->d_limb_table = nullptr; s->d_done = nullptr; s->d_prof = nullptr; s->d_accum_alt = nullptr; s->defer = 0;
+    if (hipMalloc(&s->d_accum_alt, (LG_NUM_REWARD_TERMS + 2) * sizeof(float)) != hipSuccess || hipMemset(s->d_accum_alt, 0, (LG_NUM_REWARD_TERMS + 2) * sizeof(float)) != hipSuccess) { delete s; return fail(-10, "hipMalloc failed"); }
     {   // [0] the workgroup ticket, [1 ..] one terrain-level partial sum per workgroup of k_step (at most 4 lanes per env)
-        const size_t n_done = 1 + ((size_t)params->num_envs * 4 + LG_BLOCK - 1) / LG_BLOCK;
+        const size_t n_done = 1 + 2 * (((size_t)params->num_envs * 4 + LG_BLOCK - 1) / LG_BLOCK);      // (two slots of partials, by step parity)
         if (hipMalloc(&s->d_done, n_done * sizeof(unsigned int)) != hipSuccess || hipMemset(s->d_done, 0, n_done * sizeof(unsigned int)) != hipSuccess) { delete s; return fail(-10, "hipMalloc failed"); }
     }
     memset(&s->B, 0, sizeof s->B);
@@ -2859,6 +2892,7 @@ void lg_destroy(lg_sim *s) {
     if (s->d_limb_table) (void)hipFree(s->d_limb_table);
     if (s->d_weights) (void)hipFree(s->d_weights);
     if (s->d_done) (void)hipFree(s->d_done);
+    if (s->d_accum_alt) (void)hipFree(s->d_accum_alt);
     if (s->d_prof) (void)hipFree(s->d_prof);
     delete s;
 }
@@ -2965,6 +2999,25 @@ int lg_reset_idx(lg_sim *s, const int32_t *env_ids, int32_t count, int64_t commo
         hipLaunchKernelGGL((k_reset<CassieTraits, false>), g, b, 0, st, a);
     }
     hipLaunchKernelGGL(k_extras, dim3(1), dim3(64), 0, st, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int lg_set_deferred_extras(lg_sim *s, int32_t on) {
+    if (!s) return fail(-1, "null argument");
+    s->defer = on ? 1 : 0;
+    return 0;
+}
+
+int lg_extras_flush(lg_sim *s, int64_t common_step_counter, void *stream) {
+    if (!s || !s->bound) return fail(-8, "lg_bind has not been called");
+    KArgs a; fill_args(s, a, common_step_counter);
+    // the level partial sums exist when the step kernel runs with helper waves (lg_step's choice of waves per workgroup)
+    const int nwg = s->kind == ROBOT_ANYMAL ? grid_for<AnymalTraits>(s->P.num_envs) : grid_for<CassieTraits>(s->P.num_envs);
+    const bool net = s->P.control_type == LG_CTRL_ACTUATOR_NET;
+    const int nw = (s->kind == ROBOT_ANYMAL && net) ? LG_STEP_WAVES : waves_for((unsigned)nwg, s->num_cus);
+    a.flush_parts = (nw > 1 && s->P.terrain_curriculum && s->B.terrain_levels) ? nwg : 0;
+    hipLaunchKernelGGL(k_extras, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }

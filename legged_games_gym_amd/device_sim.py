@@ -58,6 +58,14 @@ class DeviceSim:
         self._obs_out = obs
         self.sim.set_obs_buffer(obs.data_ptr())
 
+    def set_deferred_extras(self, on: bool):
+        """``lg_set_deferred_extras``: steps leave extras["episode"] to the next step's launch (rollout graphs); see flush_extras."""
+        self.sim.set_deferred_extras(on)
+
+    def flush_extras(self, counter: int = -1):
+        """``lg_extras_flush``: publish what the last deferred step left (capturable: the last node of a rollout graph)."""
+        self.sim.extras_flush(counter, self._stream())
+
     def step(self, actions: torch.Tensor, counter: int):
         if actions.dtype != torch.float32 or not actions.is_contiguous() or actions.device != self.device:
             actions = actions.to(device=self.device, dtype=torch.float32).contiguous()

@@ -28,6 +28,10 @@ from legged_games_gym_amd.device_sim import DeviceSim
 from legged_games_gym_amd.envs.base.base_task import BaseTask
 from legged_games_gym_amd.utils import packing
 from legged_games_gym_amd.utils.helpers import class_to_dict
+
+# Captured rollouts leave extras["episode"] of a step to the NEXT step's launch and end with one flush node ("deferred
+# extras"); LG_DEFER_EXTRAS=0 keeps the in-launch finisher in graphs too.
+_DEFER_EXTRAS = os.environ.get("LG_DEFER_EXTRAS", "1") != "0"
 from legged_games_gym_amd.utils.model_compiler import load_model
 from legged_games_gym_amd.utils.terrain import Terrain
 
@@ -113,9 +117,16 @@ class LeggedRobot(BaseTask):
             raise NotImplementedError("commands.curriculum needs eager steps (host-side rule between steps)")
         self._sim.buf["step_counter"].fill_(self.common_step_counter)
         self._capturing = True
+        self._sim.set_deferred_extras(_DEFER_EXTRAS)      # captured steps leave extras["episode"] to the next launch ...
+
+    def capture_extras_flush(self):
+        """Last node of a captured rollout: publish the extras["episode"] of its last step (``lg_extras_flush``)."""
+        if _DEFER_EXTRAS:
+            self._sim.flush_extras(-1)
 
     def end_graph_capture(self, steps_captured: int):
         self._capturing = False
+        self._sim.set_deferred_extras(False)               # ... eager steps publish them before they return, as the reference does
         self.common_step_counter -= steps_captured      # capture does not execute; replays are accounted by the caller
 
     def make_graphed_step(self, policy_act, warmup=3, steps_per_replay=1):
@@ -136,9 +147,15 @@ class LeggedRobot(BaseTask):
                 self.common_step_counter += 1
         torch.cuda.current_stream(self.device).wait_stream(side)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            for _ in range(steps_per_replay):                # several policy steps per hipGraphLaunch: no host in between
-                sim.step(policy_act(self.obs_buf), -1)
+        sim.set_deferred_extras(_DEFER_EXTRAS)
+        try:
+            with torch.cuda.graph(graph):
+                for _ in range(steps_per_replay):                # several policy steps per hipGraphLaunch: no host in between
+                    sim.step(policy_act(self.obs_buf), -1)
+                if _DEFER_EXTRAS:
+                    sim.flush_extras(-1)                         # extras["episode"] of the replay's last step
+        finally:
+            sim.set_deferred_extras(False)
         self._step_graph = graph
 
         def replay():
@@ -163,9 +180,15 @@ class LeggedRobot(BaseTask):
                 self.common_step_counter += 1
         torch.cuda.current_stream(self.device).wait_stream(side)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            for _ in range(steps_per_replay):
-                sim.step_policy(fused_actor, self.obs_buf, -1)
+        sim.set_deferred_extras(_DEFER_EXTRAS)
+        try:
+            with torch.cuda.graph(graph):
+                for _ in range(steps_per_replay):
+                    sim.step_policy(fused_actor, self.obs_buf, -1)
+                if _DEFER_EXTRAS:
+                    sim.flush_extras(-1)
+        finally:
+            sim.set_deferred_extras(False)
         self._step_graph = graph
 
         def replay():

@@ -169,6 +169,8 @@ class OnPolicyRunner:
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
                     obs, cobs = self._rollout_steps(stats)
+                    if hasattr(env, "capture_extras_flush"):
+                        env.capture_extras_flush()          # extras["episode"] of the rollout's last step (its steps defer them)
                 env.end_graph_capture(self.num_steps_per_env)
                 captured = False
                 assert env._obs_flip == flip0 and env.common_step_counter == counter0
@@ -178,6 +180,7 @@ class OnPolicyRunner:
             print(f"[runner] graphed rollout unavailable ({type(exc).__name__}: {exc}); using eager steps")
             if hasattr(env, "_capturing"):
                 env._capturing = False
+                env._sim.set_deferred_extras(False)
             if captured:
                 # steps issued during a capture that failed part-way were counted but never executed: put the observation
                 # ping-pong and the step counter (push / resample / RNG phase) back where they were

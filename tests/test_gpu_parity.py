@@ -434,3 +434,53 @@ def test_cassie_rough_soak_stays_finite():
             assert np.isfinite(r).all() and np.isfinite(get(d, "obs_buf")).all()
             wmax = max(wmax, float(np.abs(r[:, 10:13]).max()))
     assert wmax < 80.0, wmax
+
+
+@pytest.mark.parametrize("task,N", [("anymal_c_flat", 4096), ("anymal_c_rough", 600), ("cassie", 8200)])
+def test_deferred_extras_publish_the_same_episode_means(task, N):
+    """lg_set_deferred_extras (rollout graphs): a step leaves its finished episodes' sums to the NEXT step's launch and the last step's to
+    lg_extras_flush.  Two device sims from the same state, 40 steps of large random actions (many resets): every state buffer stays
+    bit-identical to the default mode, and after the flush episode_means agree (float atomics: tolerance) -- on the plane, on a
+    curriculum height field (level partial sums by step parity) and at a size where lg_step drops to 2 waves per workgroup."""
+    from legged_games_gym_amd.device_sim import DeviceSim
+    terr = _rough_terrain(N) if task == "anymal_c_rough" else None
+
+    def tweak(cfg):
+        if terr is not None:
+            cfg.terrain.mesh_type, cfg.terrain.num_rows, cfg.terrain.num_cols, cfg.terrain.border_size = "heightfield", 4, 5, 5
+    cfg, robot, p, names, model, w = make_setup(task, N, tweak=tweak, terrain=terr, plane=(terr is None))
+    sims = [DeviceSim(p, model, robot, torch.device("cuda:0"), w) for _ in range(2)]
+    rng = np.random.default_rng(0)
+    lv, ty = rng.integers(0, 4, N).astype(np.int32), (np.arange(N) * 5 // N).astype(np.int32)
+    ep_len0 = rng.integers(900, 1000, N)                                      # time-outs on the way
+    fr, dm = randomize_env_params(N, 3)
+    for d in sims:
+        if terr is not None:
+            d.set_terrain(terr.heightsamples, terr.env_origins)
+            d.buf["terrain_levels"].copy_(torch.from_numpy(lv)); d.buf["terrain_types"].copy_(torch.from_numpy(ty))
+        origins = terr.env_origins[lv, ty].astype(np.float32) if terr is not None else grid_origins(N)
+        d.buf["env_origins"].copy_(torch.from_numpy(origins)); d.buf["friction_coeffs"].copy_(torch.from_numpy(fr).view(d.buf["friction_coeffs"].shape))
+        d.buf["base_mass_delta"].copy_(torch.from_numpy(dm).view(d.buf["base_mass_delta"].shape))
+        d.reset_idx(torch.arange(N, dtype=torch.int32), 0)
+        d.buf["episode_length_buf"].copy_(torch.from_numpy(ep_len0).to(d.buf["episode_length_buf"].dtype))
+    eager, deferred = sims
+    deferred.set_deferred_extras(True)
+    g = torch.Generator().manual_seed(2)
+    means = []
+    for it in range(1, 41):
+        act = (torch.randn(N, robot.num_dof, generator=g) * 2.0).float().cuda()
+        eager.step(act, it); deferred.step(act, it)
+        means.append(get(eager, "episode_means").copy())
+        if it == 20:                                                          # a flush in the middle of a run is harmless
+            deferred.flush_extras(it)
+            np.testing.assert_allclose(get(deferred, "episode_means"), means[-1], rtol=2e-5, atol=1e-6)
+    assert int(get(eager, "reset_buf").sum()) >= 0 and sum(int((m != means[0]).any()) for m in means) > 5      # the means did move
+    deferred.flush_extras(40)
+    for k in ("root_states", "dof_state", "obs_buf", "rew_buf", "reset_buf", "episode_length_buf", "episode_sums", "commands", "terrain_levels", "step_counter"):
+        if k in eager.buf:
+            assert np.array_equal(get(eager, k), get(deferred, k)), k
+    np.testing.assert_allclose(get(deferred, "episode_means"), means[-1], rtol=2e-5, atol=1e-6)
+    # one step late without a flush: after step 41 the deferred sim shows what the default showed after step 40 (if step 40 had finished episodes)
+    act = torch.zeros(N, robot.num_dof, device="cuda")
+    deferred.step(act, 41)
+    np.testing.assert_allclose(get(deferred, "episode_means")[:-1], means[-1][:-1], rtol=2e-5, atol=1e-6)

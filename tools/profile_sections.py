@@ -36,6 +36,9 @@ if "nosc" in sys.argv:                      # anymal_c_flat without self-collisi
     env_cfg.asset.self_collisions = 1
 env, cfg = task_registry.make_env(task, args, env_cfg=env_cfg)
 print("self-collision:", env.self_collision_modelled)
+if "defer" in sys.argv:                     # lg_set_deferred_extras(1): no finisher in the launch (the previous step's is done by workgroup 0)
+    env._sim.set_deferred_extras(True)
+    print("deferred extras: on")
 lib = capi.load_library()
 lib.lg_debug_profile.argtypes, lib.lg_debug_profile.restype = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int], ctypes.c_int
 out = (ctypes.c_uint64 * 20)()
