@@ -331,7 +331,8 @@ def worker(a):
             "config": {"workload": workload_text(a.task, env, pol, a.num_envs),
                        "envs_per_gpu": a.num_envs, "decimation": int(env.cfg.control.decimation), "sim_dt": float(env.sim_params.dt),
                        "parallelism": f"env-sharded x{world}", "state_finite": finite,
-                       "launch": ("eager" if a.no_graph else f"HIP graph of {G} policy steps per replay") + (": ONE kernel, actor fused into the step (lg_step_policy)" if fused_step else " (policy + lg_step)"),
+                       "launch": ("eager" if a.no_graph else f"HIP graph of {G} policy steps per replay") + (": ONE kernel per step, actor fused into the step (lg_step_policy)" if fused_step else " (policy + lg_step)")
+                                 + ("" if a.no_graph or os.environ.get("LG_DEFER_EXTRAS", "1") == "0" else "; extras[\"episode\"] deferred to the next launch, one lg_extras_flush node per replay"),
                        "policy": "torch ops (hipBLASLt)" if use_torch else ("MFMA actor inside k_step (v_mfma_f32_16x16x4_f32, 4 waves)" if fused_step else "actor kernel lg_policy_act: k_policy_act_wide, 32 envs per workgroup, split-bf16 products (hi*hi + hi*lo + lo*hi, f32 accumulate) on v_mfma_f32_32x32x16_bf16")},
             "repeats": repeats,
             "timing": f"median of {repeats} timed regions of exactly {a.steps} steps each (a region shorter than {a.min_timed_ms:g} ms is repeated)" if repeats > 1 else f"one timed region of {a.steps} steps",
