@@ -36,6 +36,17 @@ from legged_games_gym_amd.utils.model_compiler import load_model
 from legged_games_gym_amd.utils.terrain import Terrain
 
 
+def command_curriculum_update(mean_episode_sum, max_episode_length, tracking_scale_dt, lin_vel_x, max_curriculum):
+    """``update_command_curriculum`` (reference :471-483): widen the ``lin_vel_x`` range by 0.5 on both sides, clipped at
+    ``max_curriculum``, when the mean tracking reward of the reset envs exceeds 80 % of its maximum.  Pure host arithmetic;
+    pinned by tests/golden/command_curriculum.npz (the reference's own method)."""
+    lo, hi = float(lin_vel_x[0]), float(lin_vel_x[1])
+    if mean_episode_sum / max_episode_length > 0.8 * tracking_scale_dt:
+        lo = float(np.clip(lo - 0.5, -max_curriculum, 0.0))
+        hi = float(np.clip(hi + 0.5, 0.0, max_curriculum))
+    return [lo, hi]
+
+
 class LeggedRobot(BaseTask):
     def __init__(self, cfg, sim_params, physics_engine, sim_device, headless):
         self.cfg = cfg
@@ -104,10 +115,10 @@ class LeggedRobot(BaseTask):
             return
         i = self.reward_names_all.index("tracking_lin_vel")
         mean_sum = float(self._episode_means[i]) * self.max_episode_length_s
-        if mean_sum / self.max_episode_length > 0.8 * self.reward_scales["tracking_lin_vel"]:
-            r = self.command_ranges["lin_vel_x"]
-            r[0] = np.clip(r[0] - 0.5, -self.cfg.commands.max_curriculum, 0.0)
-            r[1] = np.clip(r[1] + 0.5, 0.0, self.cfg.commands.max_curriculum)
+        new = command_curriculum_update(mean_sum, self.max_episode_length, self.reward_scales["tracking_lin_vel"],
+                                        self.command_ranges["lin_vel_x"], self.cfg.commands.max_curriculum)
+        if new != list(self.command_ranges["lin_vel_x"]):
+            self.command_ranges["lin_vel_x"][:] = new
             self.set_command_ranges()
         self.extras["episode"]["max_command_x"] = self.command_ranges["lin_vel_x"][1]
 

@@ -81,11 +81,49 @@ def synth_state(robot, p, N, seed, with_heights=False, hf=None):
     return st
 
 
+def full_case_inputs(robot, cfg, N, seed, terrain):
+    """Inputs of the G5 fixtures (tools/make_golden.py:g5) beyond ``synth_state``: env origins, terrain levels / types with robots
+    at every distance from their origin (all three branches of _update_terrain_curriculum :446-469, the solved-last-level draw and
+    the clip at level 0), running episode sums, and episode lengths that hit the command-resampling interval."""
+    import torch
+    from legged_games_gym_amd.utils import packing
+    st = synth_state(robot, None, N, seed)
+    g = torch.Generator().manual_seed(seed + 1000)
+    dt = cfg.control.decimation * cfg.sim.dt
+    st["episode_length_buf"][::5] = int(cfg.commands.resampling_time / dt) * 2 - 1      # resampled after the increment (:333-335)
+    R = len(packing.reward_layout(cfg, dt)[2])
+    ts = {"episode_sums": (torch.randn(R, N, generator=g) * 3.0).float()}
+    if terrain is None:
+        ts["env_origins"] = torch.from_numpy(grid_origins(N))
+    else:
+        rows, cols = cfg.terrain.num_rows, cfg.terrain.num_cols
+        ts["terrain_types"] = torch.div(torch.arange(N), (N / cols), rounding_mode="floor").to(torch.long)      # :764-766
+        ts["terrain_levels"] = torch.randint(0, rows, (N,), generator=g)
+        org = torch.from_numpy(terrain.env_origins).float()[ts["terrain_levels"], ts["terrain_types"]]
+        ts["env_origins"] = org.clone()
+        r, a = torch.rand(N, generator=g) * 6.0, torch.rand(N, generator=g) * 6.2831853
+        st["root_states"][:, 0] = org[:, 0] + r * torch.cos(a)
+        st["root_states"][:, 1] = org[:, 1] + r * torch.sin(a)
+        st["root_states"][:, 2] += org[:, 2]
+    return st, ts
+
+
 def golden_tweak(kind):
     """Config edits shared by the G4 fixture generator (applied to the REFERENCE's config classes) and by the tests that
     replay the fixtures (applied to this repo's config classes).  RNG consumers are switched off: the reference draws from
     torch's global generator, the build from Philox."""
     def tweak(cfg):
+        if kind.startswith("full_"):
+            # G5: nothing is switched off -- noise, pushes, command resampling and reset_idx all run, their draws keyed by
+            # tests/philox_np.py; small terrains keep the fixtures small
+            if kind == "full_anymal_c_rough":
+                cfg.terrain.mesh_type, cfg.terrain.num_rows, cfg.terrain.num_cols, cfg.terrain.border_size = "heightfield", 4, 3, 5
+                cfg.terrain.curriculum = True
+            elif kind == "full_cassie":
+                cfg.terrain.mesh_type, cfg.terrain.num_rows, cfg.terrain.num_cols, cfg.terrain.border_size = "heightfield", 2, 2, 5
+                cfg.terrain.curriculum = False
+                cfg.domain_rand.push_interval_s = 0.02 * 751          # the fixture's step is a push step
+            return
         cfg.noise.add_noise = False
         cfg.domain_rand.push_robots = False
         cfg.commands.resampling_time = 1.0e6           # no resampling in the fixtures

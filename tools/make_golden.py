@@ -40,6 +40,28 @@ REF = os.environ.get("LG_REFERENCE_DIR", "/root/reference")
 OUT = os.path.join(REPO, "tests", "golden")
 os.makedirs(OUT, exist_ok=True)
 
+# every reference file whose text is executed here, with the SHA-256 of what was read: stored in each fixture
+# (``reference_sha256``) and re-checked by tests/test_golden_provenance.py whenever /root/reference is present
+EXECUTED = {}
+
+
+def read_reference(rel):
+    import hashlib
+    path = os.path.join(REF, rel)
+    text = open(path).read()
+    EXECUTED[rel] = hashlib.sha256(text.encode()).hexdigest()
+    return path, text
+
+
+def record_provenance(*fixtures):
+    """tests/golden/provenance.json: fixture file -> {reference file: sha256 of the text that was executed for it}."""
+    path = os.path.join(OUT, "provenance.json")
+    table = json.load(open(path)) if os.path.isfile(path) else {}
+    for f in fixtures:
+        table[f] = dict(sorted(EXECUTED.items()))
+    with open(path, "w") as fh:
+        json.dump(dict(sorted(table.items())), fh, indent=1)
+
 
 def ref_class_to_dict(obj):
     """helpers.py:41-56 semantics (dir() order), re-stated to avoid importing isaacgym."""
@@ -63,9 +85,9 @@ def load_reference_configs():
         return m
 
     def run(name, rel):
-        path = os.path.join(REF, rel)
+        path, text = read_reference(rel)
         m = mod(name, path)
-        exec(compile(open(path).read(), path, "exec"), m.__dict__)
+        exec(compile(text, path, "exec"), m.__dict__)
         return m
     for pkg in ("legged_gym", "legged_gym.envs", "legged_gym.envs.base", "legged_gym.envs.anymal_c",
                 "legged_gym.envs.anymal_c.mixed_terrains", "legged_gym.envs.anymal_c.flat", "legged_gym.envs.cassie"):
@@ -92,11 +114,13 @@ def load_reference_configs():
 
 
 def g2():
+    EXECUTED.clear()
     out = {}
     for name, (E, T) in load_reference_configs().items():
         out[name] = {"env": ref_class_to_dict(E()), "train": ref_class_to_dict(T())}
     with open(os.path.join(OUT, "configs.json"), "w") as fh:
         json.dump(out, fh, indent=1, sort_keys=False)
+    record_provenance("configs.json")
     print("G2 configs.json:", {k: (v["env"]["env"]["num_observations"], len([s for s in v["env"]["rewards"]["scales"].values() if s != 0])) for k, v in out.items()})
 
 
@@ -162,8 +186,8 @@ def g3():
 def _ref_functions(rel, class_name, namespace, want=None):
     """name -> function object for every ``def`` of ``class_name`` (or of the module when None) in a reference source file.
     The file is parsed, never imported; each def is compiled on its own inside ``namespace``."""
-    path = os.path.join(REF, rel)
-    tree = ast.parse(open(path).read(), filename=path)
+    path, text = read_reference(rel)
+    tree = ast.parse(text, filename=path)
     body = tree.body
     if class_name is not None:
         body = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == class_name).body
@@ -210,18 +234,19 @@ def _external_helpers():
     return {"quat_rotate_inverse": quat_rotate_inverse, "quat_apply": quat_apply, "normalize": normalize, "torch_rand_float": torch_rand_float}
 
 
-def build_reference_env(task, N, state, tweak):
+def build_reference_env(task, N, state, tweak, extra_ns=None, extra_methods=()):
     """A plain object carrying the reference's own methods (extracted with ast) and config, filled from ``state``."""
     import torch
     from tests.common import TASK_CFG
     from legged_games_gym_amd.utils.model_compiler import load_model
     ns = {"torch": torch, "np": np}
     ns.update(_external_helpers())
+    ns.update(extra_ns or {})
     ns.update(_ref_functions("legged_gym/utils/math.py", None, ns, lambda k: k in ("quat_apply_yaw", "wrap_to_pi")))
     ns.update(_ref_functions("legged_gym/utils/helpers.py", None, ns, lambda k: k == "class_to_dict"))
     keep = _ref_functions("legged_gym/envs/base/legged_robot.py", "LeggedRobot", ns, lambda k: k.startswith("_reward_") or k in (
         "_parse_cfg", "_prepare_reward_function", "_init_height_points", "_post_physics_step_callback", "_resample_commands",
-        "check_termination", "compute_reward", "compute_observations", "_get_heights", "_compute_torques"))
+        "check_termination", "compute_reward", "compute_observations", "_get_heights", "_compute_torques") + tuple(extra_methods))
     if task == "cassie":
         keep.update(_ref_functions("legged_gym/envs/cassie/cassie.py", "Cassie", ns, lambda k: k == "_reward_no_fly"))
     Ref = type("ReferenceLeggedRobotMethods", (), keep)
@@ -295,6 +320,7 @@ G4_INPUT_KEYS = ("root_states", "dof_state", "contact_forces", "actions", "last_
 
 def g4():
     import torch
+    EXECUTED.clear()
     from tests.common import synth_state, golden_tweak, TASK_CFG
     from legged_games_gym_amd.utils.model_compiler import load_model
     ext = ["base_lin_vel", "base_ang_vel", "projected_gravity", "obs_buf", "commands", "measured_heights", "rew_buf", "episode_sums"]
@@ -357,9 +383,232 @@ def g4():
         out[f"{ctrl}_torques"] = tau.numpy()
     np.savez_compressed(os.path.join(OUT, "pd_torques.npz"), **out)
     print("G4 pd_torques.npz: |tau| max", {c: float(np.abs(out[c + "_torques"]).max()) for c in ("P", "V", "T")})
+    record_provenance("heights.npz", "pd_torques.npz", *[f"post_physics_{t}.npz" for t in ("anymal_c_flat", "cassie", "anymal_c_rough", "a1")])
+
+
+# ----------------------------------------------------------------------------- G5: the reset / RNG half
+class KeyedDraws:
+    """Stands in for torch's global generator while the reference's own reset / resample / push / noise code runs: every draw
+    is answered from the counter-based stream the build uses, keyed (seed; env, step, purpose, lane) -- tests/philox_np.py,
+    an independent numpy Philox4x32-10 checked against Random123's known answers.  The reference asks for uniforms in call
+    order; which PURPOSE a call belongs to is set by thin wrappers around the reference's methods (``scoped`` below), the
+    lane is the running position inside that purpose's stream (lane l = word l % 4 of block l // 4)."""
+
+    def __init__(self, seed, step):
+        self.seed, self.step = seed, step
+        self.purpose, self.env_ids, self.cursor = None, None, 0
+        self.log = []
+
+    def enter(self, purpose, env_ids, first_lane=0):
+        self.purpose, self.env_ids, self.cursor = purpose, np.asarray(env_ids, np.int64), first_lane
+
+    def take(self, n, m):
+        from tests import philox_np as ph
+        assert self.purpose is not None and n == len(self.env_ids), (self.purpose, n, None if self.env_ids is None else len(self.env_ids))
+        u = ph.lanes(self.seed, self.env_ids, self.step, self.purpose, self.cursor, m)
+        self.log.append((self.purpose, n, self.cursor, m))
+        self.cursor += m
+        return u
+
+
+def build_reset_env(task, N, state, tweak, seed, step, terrain=None, terrain_state=None):
+    """build_reference_env + what the reference's post_physics_step / reset_idx and their callees touch, with the simulator
+    calls as no-ops and every random draw answered by ``KeyedDraws``."""
+    import torch
+    from tests import philox_np as ph
+    draws = KeyedDraws(seed, step)
+
+    def torch_rand_float(lower, upper, shape, device):           # [EXTERNAL] isaacgym.torch_utils: (upper - lower) * rand + lower
+        n, m = shape
+        return (upper - lower) * torch.from_numpy(draws.take(n, m)) + lower
+
+    class TorchWithKeyedDraws:                                      # the reference calls torch.randint_like / torch.rand_like directly
+        def __getattr__(self, k):
+            return getattr(torch, k)
+
+        @staticmethod
+        def randint_like(t, high):                                 # level of a robot that solved the last one (:464-466)
+            u = torch.from_numpy(draws.take(t.shape[0], 1))[:, 0]
+            return torch.clamp((u * high).to(t.dtype), max=high - 1)
+
+        @staticmethod
+        def rand_like(t):                                          # observation noise (:226): the build's per-element keys
+            assert draws.purpose == ph.NOISE
+            K, L = env._robot.num_limbs, env._robot.chain_len
+            return torch.from_numpy(ph.observation_noise(seed, t.shape[0], step, t.shape[1], K, L))
+
+    env, robot, ns = build_reference_env(task, N, state, tweak, extra_ns={"torch_rand_float": torch_rand_float, "torch": TorchWithKeyedDraws(), "gymtorch": types.SimpleNamespace(unwrap_tensor=lambda t: t)},
+                                         extra_methods=("post_physics_step", "reset_idx", "_reset_dofs", "_reset_root_states", "_push_robots", "_update_terrain_curriculum",
+                                                        "update_command_curriculum", "_get_noise_scale_vec"))
+    env._robot = robot
+    cls = type(env)
+
+    def scoped(name, purpose, ids=lambda a: a[0], first_lane=lambda: 0):
+        inner = getattr(cls, name)
+
+        def wrapper(self, *a, **kw):
+            saved = (draws.purpose, draws.env_ids, draws.cursor)
+            draws.enter(purpose() if callable(purpose) else purpose, ids(a), first_lane())
+            try:
+                return inner(self, *a, **kw)
+            finally:
+                draws.purpose, draws.env_ids, draws.cursor = saved
+        setattr(cls, name, wrapper)
+    in_reset = [False]
+    inner_reset = cls.reset_idx
+
+    def reset_idx(self, env_ids):
+        in_reset[0] = True
+        try:
+            return inner_reset(self, env_ids)
+        finally:
+            in_reset[0] = False
+    cls.reset_idx = reset_idx
+    everyone = lambda a: np.arange(N)
+    scoped("_resample_commands", lambda: ph.CMD_RESET if in_reset[0] else ph.CMD_STEP)
+    scoped("_reset_dofs", ph.DOF)
+    # the build always spends lanes 0-1 of ROOT on the xy offset and 2-7 on the velocities; the reference skips the first call
+    # on the plane (custom_origins False, :427-429)
+    scoped("_reset_root_states", ph.ROOT, first_lane=lambda: 0 if env.custom_origins else 2)
+    scoped("_update_terrain_curriculum", ph.TERRAIN)
+    scoped("_push_robots", ph.PUSH, ids=everyone)
+    scoped("compute_observations", ph.NOISE, ids=everyone)
+
+    noop = lambda *a, **k: None
+    env.gym = types.SimpleNamespace(refresh_actor_root_state_tensor=noop, refresh_net_contact_force_tensor=noop, set_dof_state_tensor_indexed=noop,
+                                    set_actor_root_state_tensor_indexed=noop, set_actor_root_state_tensor=noop)
+    env.sim, env.viewer, env.enable_viewer_sync, env.debug_viz = None, None, False, False
+    env.init_done, env.extras, env.num_dof = True, {}, robot.num_dof
+    i = env.cfg.init_state
+    env.base_init_state = torch.tensor(i.pos + i.rot + i.lin_vel + i.ang_vel, dtype=torch.float)
+    env.last_root_vel = torch.zeros(N, 6)
+    env.obs_buf = torch.zeros(N, env.cfg.env.num_observations)
+    env.noise_scale_vec = env._get_noise_scale_vec(env.cfg)      # also sets add_noise from the config (:495)
+    env.common_step_counter = step - 1                           # post_physics_step increments it first (:115)
+    if terrain is not None:
+        env.custom_origins = True
+        env.terrain = types.SimpleNamespace(cfg=env.cfg.terrain, env_length=env.cfg.terrain.terrain_length)
+        env.height_samples = torch.from_numpy(terrain.heightsamples.astype(np.int64))
+        env.terrain_origins = torch.from_numpy(terrain.env_origins).to(torch.float)
+        env.max_terrain_level = env.cfg.terrain.num_rows
+        env.terrain_levels = terrain_state["terrain_levels"].clone()
+        env.terrain_types = terrain_state["terrain_types"].clone()
+    else:
+        env.custom_origins = False
+    env.env_origins = terrain_state["env_origins"].clone()
+    return env, robot, ns, draws
+
+
+G5_STATE_OUT = ("root_states", "dof_state", "commands", "last_actions", "last_dof_vel", "last_root_vel", "feet_air_time", "last_contacts",
+                "episode_length_buf", "reset_buf", "time_out_buf", "rew_buf", "obs_buf", "base_lin_vel", "base_ang_vel", "projected_gravity", "env_origins")
+
+
+def g5_case(task, kind, N, seed, step, state_seed):
+    """One full-post-physics fixture: the reference's own post_physics_step (:106-137) INCLUDING the command resampling, the push,
+    reset_idx with the terrain curriculum, and the observation noise."""
+    import torch
+    from tests.common import synth_state, golden_tweak, TASK_CFG, full_case_inputs
+    from legged_games_gym_amd.utils.model_compiler import load_model
+    from legged_games_gym_amd.utils.terrain import Terrain
+    tw = golden_tweak(kind)
+    mine = TASK_CFG[task](); tw(mine)
+    robot = load_model(mine.asset.file)
+    terr = None
+    if mine.terrain.mesh_type != "plane":
+        np.random.seed(3)
+        terr = Terrain(mine.terrain, N)
+    st, ts = full_case_inputs(robot, mine, N, state_seed, terr)
+    env, robot, ns, draws = build_reset_env(task, N, st, tw, seed, step, terrain=terr, terrain_state=ts)
+    names = list(env.reward_scales.keys())
+    for i, k in enumerate(names):
+        env.episode_sums[k][:] = ts["episode_sums"][i]
+    env.post_physics_step()
+    env.obs_buf = torch.clip(env.obs_buf, -env.cfg.normalization.clip_observations, env.cfg.normalization.clip_observations)   # step :100-101
+    out = {"in_" + k: st[k].numpy() for k in G4_INPUT_KEYS}
+    out.update({"in_env_origins": ts["env_origins"].numpy(), "in_episode_sums": ts["episode_sums"].numpy()})
+    if terr is not None:
+        out.update(height_samples=terr.heightsamples, terrain_origins=terr.env_origins, in_terrain_levels=ts["terrain_levels"].numpy(),
+                   in_terrain_types=ts["terrain_types"].numpy(), terrain_levels=env.terrain_levels.numpy())
+    for k in G5_STATE_OUT:
+        out[k] = getattr(env, k).numpy()
+    ep = env.extras.get("episode", {})
+    out.update(measured_heights=(env.measured_heights.numpy() if terr is not None else np.zeros(0, np.float32)),
+               episode_sums=np.stack([env.episode_sums[k].numpy() for k in names]), reward_names=np.array(names),
+               episode_means=np.array([float(ep["rew_" + k]) for k in names], np.float32),
+               terrain_level_mean=np.float32(float(ep["terrain_level"]) if "terrain_level" in ep else -1.0),
+               extras_time_outs=env.extras["time_outs"].numpy(), seed=np.int64(seed), step=np.int64(step), kind=np.array(kind),
+               draw_log=np.array(draws.log, np.int64),
+               external_helper_arrays=np.array(["base_lin_vel", "base_ang_vel", "projected_gravity", "obs_buf", "commands", "measured_heights", "rew_buf", "episode_sums",
+                                                "root_states", "dof_state"]))
+    name = f"post_physics_full_{kind[5:]}.npz"
+    np.savez_compressed(os.path.join(OUT, name), **out)
+    rs = env.reset_buf.numpy().astype(bool)
+    purposes = sorted(set(int(l[0]) for l in draws.log))
+    print(f"G5 {name}: resets {int(rs.sum())}/{N}, draw purposes {purposes}" + (f", level changes {np.bincount((env.terrain_levels.numpy() - ts['terrain_levels'].numpy())[rs] + 3, minlength=7).tolist()}" if terr is not None and mine.terrain.curriculum else ""))
+    return name
+
+
+def g5():
+    import torch
+    EXECUTED.clear()
+    from tests.common import synth_state, golden_tweak, TASK_CFG, full_case_inputs
+    from legged_games_gym_amd.utils.model_compiler import load_model
+    made = [g5_case("anymal_c_flat", "full_anymal_c_flat", 193, seed=1, step=1500, state_seed=31),
+            g5_case("anymal_c_rough", "full_anymal_c_rough", 180, seed=0x5DEECE66D, step=2250, state_seed=32),
+            g5_case("cassie", "full_cassie", 150, seed=77, step=751, state_seed=33)]
+
+    # stand-alone reset_idx(env_ids) (what lg_reset_idx replaces): a subset of envs, plane and curriculum terrain
+    for task, kind, N, seed, step in (("anymal_c_flat", "full_anymal_c_flat", 64, 5, 9), ("anymal_c_rough", "full_anymal_c_rough", 90, 6, 4000)):
+        from legged_games_gym_amd.utils.terrain import Terrain
+        tw = golden_tweak(kind)
+        mine = TASK_CFG[task](); tw(mine)
+        robot = load_model(mine.asset.file)
+        terr = None
+        if mine.terrain.mesh_type != "plane":
+            np.random.seed(3)
+            terr = Terrain(mine.terrain, N)
+        st, ts = full_case_inputs(robot, mine, N, 40 + N, terr)
+        env, robot, ns, draws = build_reset_env(task, N, st, tw, seed, step, terrain=terr, terrain_state=ts)
+        names = list(env.reward_scales.keys())
+        for i, k in enumerate(names):
+            env.episode_sums[k][:] = ts["episode_sums"][i]
+        env.reset_buf = torch.zeros(N, dtype=torch.bool)
+        env.time_out_buf = torch.zeros(N, dtype=torch.bool)
+        ids = torch.from_numpy(np.sort(np.random.default_rng(N).choice(N, N // 3, replace=False)))
+        env.reset_idx(ids)
+        out = {"in_" + k: st[k].numpy() for k in G4_INPUT_KEYS}
+        out.update({"in_env_origins": ts["env_origins"].numpy(), "in_episode_sums": ts["episode_sums"].numpy(), "env_ids": ids.numpy()})
+        if terr is not None:
+            out.update(height_samples=terr.heightsamples, terrain_origins=terr.env_origins, in_terrain_levels=ts["terrain_levels"].numpy(),
+                       in_terrain_types=ts["terrain_types"].numpy(), terrain_levels=env.terrain_levels.numpy())
+        for k in ("root_states", "dof_state", "commands", "last_actions", "last_dof_vel", "feet_air_time", "episode_length_buf", "reset_buf", "env_origins"):
+            out[k] = getattr(env, k).numpy()
+        ep = env.extras["episode"]
+        out.update(episode_sums=np.stack([env.episode_sums[k].numpy() for k in names]), reward_names=np.array(names),
+                   episode_means=np.array([float(ep["rew_" + k]) for k in names], np.float32),
+                   terrain_level_mean=np.float32(float(ep["terrain_level"]) if "terrain_level" in ep else -1.0), seed=np.int64(seed), step=np.int64(step), kind=np.array(kind))
+        name = f"reset_idx_{task}.npz"
+        np.savez_compressed(os.path.join(OUT, name), **out)
+        made.append(name)
+        print(f"G5 {name}: {len(ids)} of {N} envs reset")
+
+    # update_command_curriculum (:471-483): the range rule on both sides of its threshold, clipped at max_curriculum
+    st = synth_state(load_model(TASK_CFG["anymal_c_flat"]().asset.file), None, 16, seed=1)
+    env, robot, ns = build_reference_env("anymal_c_flat", 16, st, golden_tweak("anymal_c_flat"), extra_methods=("update_command_curriculum",))
+    rows = []
+    for frac, lo, hi in ((0.79, -1.0, 1.0), (0.81, -1.0, 1.0), (0.9, -0.8, 0.7), (0.95, -1.0, 1.0), (0.95, 0.0, 0.2)):
+        env.command_ranges["lin_vel_x"] = [lo, hi]
+        env.episode_sums["tracking_lin_vel"][:] = frac * env.reward_scales["tracking_lin_vel"] * env.max_episode_length
+        env.update_command_curriculum(torch.arange(16))
+        rows.append((frac, lo, hi, float(env.command_ranges["lin_vel_x"][0]), float(env.command_ranges["lin_vel_x"][1])))
+    np.savez(os.path.join(OUT, "command_curriculum.npz"), rows=np.array(rows, np.float64), max_curriculum=np.float64(env.cfg.commands.max_curriculum),
+             max_episode_length=np.float64(env.max_episode_length), scale_dt=np.float64(env.reward_scales["tracking_lin_vel"]))
+    made.append("command_curriculum.npz")
+    print("G5 command_curriculum.npz:", rows)
+    record_provenance(*made)
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g2", "g1", "g3", "g4"]
+    which = sys.argv[1:] or ["g2", "g1", "g3", "g4", "g5"]
     for w in which:
-        {"g1": g1, "g2": g2, "g3": g3, "g4": g4}[w]()
+        {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5": g5}[w]()
