@@ -65,6 +65,9 @@ def parse_args():
     return a
 
 
+PPO_LEG_FAILED = 3      # exit code of a rank whose PPO leg raised or stalled at N > 1 (after the headline line was printed)
+
+
 def spawn_workers(a):
     """`python bench.py --gpus N` without a launcher: N worker processes, one per GPU, started BEFORE anything touches a GPU."""
     with socket.socket() as s:
@@ -86,6 +89,8 @@ def spawn_workers(a):
                 procs.remove(p)
                 if code != 0:
                     rc = rc or code
+                    if code == PPO_LEG_FAILED:   # its headline work is done; the other ranks leave the leg through their own watchdog
+                        continue                 # (rank 0 still has the line to print) and the job ends non-zero
                     for q in procs:          # a dead rank leaves the others in a collective: stop them (exact PIDs)
                         q.terminate()
             time.sleep(0.05)
@@ -378,7 +383,7 @@ def worker(a):
                 return
             emit({"error": f"PPO leg did not finish within {limit:g} s at world size {world}: abandoned, headline line unaffected"})
             sys.stdout.flush()
-            os._exit(0)
+            os._exit(PPO_LEG_FAILED)                  # the line is out, but a stalled collective is not a success: non-zero for the driver
         timer = threading.Timer(limit, abandon)
         timer.daemon = True
         if world > 1:
@@ -394,7 +399,7 @@ def worker(a):
     if world > 1:
         if broken:                               # the other ranks may still sit in a collective of the leg: do not join them again
             sys.stdout.flush()
-            os._exit(0)
+            os._exit(PPO_LEG_FAILED)
         dist.barrier()
         dist.destroy_process_group()
 

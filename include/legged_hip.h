@@ -360,6 +360,20 @@ int  lg_ppo_loss(const float *mu, const float *std, const float *value, const in
                  int32_t use_clipped_value, float *d_mu, float *d_std, float *d_value, float *stats, int32_t mb, int32_t num_actions,
                  void *stream);
 
+/* Sticky device status.  The workgroups of lg_step hand data between their waves through LDS flags with BOUNDED polls; a poll
+ * that runs out (never observed; it would mean a lost store or a scheduling fault) lets the wave go on -- a hung CU is worse --
+ * but ORs a bit into a host-mapped status word of the handle.  From then on EVERY call on the handle returns -20 (text in
+ * lg_last_error()) until lg_clear_device_status(): rc 0 never covers a step whose physics missed a hand-over once the host has
+ * seen the word, i.e. at the latest on the first call after the next synchronisation.  lg_device_status() returns the word
+ * (>= 0; 0 = clean), optionally after hipDeviceSynchronize().  No counterpart in the reference (PhysX reports nothing).
+ * lg_debug_handover() is the test hook that provokes the condition (skip: 1 = frame flag withheld, 2 = self-collision flags
+ * withheld; spin_limit: poll bound, <= 0 restores 2^22). */
+#define LG_STATUS_FRAME_HANDOVER_TIMEOUT  0x1u
+#define LG_STATUS_SELF_COLLISION_TIMEOUT  0x2u
+int  lg_device_status(lg_sim *sim, int32_t synchronize);
+int  lg_clear_device_status(lg_sim *sim);
+int  lg_debug_handover(lg_sim *sim, int32_t skip, int32_t spin_limit);
+
 const char *lg_last_error(void);
 int  lg_abi_version(void);
 /* sizeof of the ABI structs (0 params, 1 robot_model, 2 buffers, 3 point, 4 mlp_net, 5 adam_tensor, 6 rollout_step, 7 ppo_batch;

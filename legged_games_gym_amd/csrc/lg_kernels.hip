@@ -87,7 +87,17 @@ struct KArgs {                 // passed by value: lives in the kernarg segment 
     int64_t    step;
     PolicyArgs pol;               // fused rollout step (k_step<..., POL = true>): the actor that produces this step's actions
     unsigned long long *prof;     // LG_PROFILE builds only: [LG_NPROF] cycle accumulators (tools/profile_sections.py)
+    unsigned int *status;         // sticky device status word (host-mapped): LG_STATUS_* bits, see lg_device_status()
+    int   spin_limit;             // bound of the LDS hand-over polls (s_sleep rounds); lg_debug_handover() shrinks it
+    int   debug_skip;             // test hook: 1 = the rigid-body wave withholds the frame hand-over flag, 2 = the helpers withhold the self-collision flags
 };
+
+// A hand-over poll that ran out must not pass silently (rc 0 with wrong physics is the worst failure this library can have): the
+// wave ORs a bit into the host-visible status word and goes on (a hung CU would be worse); every later C-ABI call on the handle
+// fails with that status until lg_clear_device_status().
+LG_DEV void lg_report(unsigned int *status, unsigned int bit) {
+    if (status) __hip_atomic_fetch_or(status, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // ------------------------------------------------------------------ section profiler (debug builds: -DLG_PROFILE)
 #define LG_NPROF 20
@@ -603,7 +613,7 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, int lane_k, float 
                 fkout[j][3][ln] = make_float4(vj.x, vj.y, vj.z, 0.0f);
                 if (j == L - 1) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    if (ln == 0) *fk_ready = substep_no;
+                    if (ln == 0 && A.debug_skip != 1) *fk_ready = substep_no;
                 }
             }
 #pragma unroll
@@ -670,11 +680,13 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, int lane_k, float 
             const int ln = threadIdx.x % LG_BLOCK;
             if (sc_on_helpers) {                           // detection ran on the helper waves during the first pass
                 volatile int4 *rdy = reinterpret_cast<volatile int4 *>(sc->ready);       // one read covers the three helpers' flags
-                for (int spin = 0; spin < (1 << 22); spin++) {                             // bounded, like the fk hand-over
+                bool arrived = false;
+                for (int spin = 0; spin < A.spin_limit; spin++) {                          // bounded, like the fk hand-over
                     const int r1 = rdy->y, r2 = rdy->z, r3 = rdy->w;
-                    if (min(r1, min(r2, r3)) >= substep_no) break;
+                    if (min(r1, min(r2, r3)) >= substep_no) { arrived = true; break; }
                     __builtin_amdgcn_s_sleep(1);
                 }
+                if (!arrived && ln == 0) lg_report(A.status, LG_STATUS_SELF_COLLISION_TIMEOUT);
                 __builtin_amdgcn_wave_barrier();
             } else {
                 __builtin_amdgcn_wave_barrier();           // this wave's own LDS writes (kinematics loop) precede the reads: one wave, in order
@@ -1276,7 +1288,8 @@ template <class T, bool NET, bool HF, int NW, bool SC = false> struct HelperWave
                     volatile int *flag = &sh.fk_ready;
                     // bounded: ~0.3 s at most, then go on with whatever is in LDS (wrong numbers beat a hung CU; the rigid-body
                     // wave publishes the flag unconditionally every sub-step, so the bound is never reached in a correct run)
-                    for (int spin = 0; *flag < it + 1 && spin < (1 << 22); spin++) __builtin_amdgcn_s_sleep(1);
+                    for (int spin = 0; *flag < it + 1 && spin < A.spin_limit; spin++) __builtin_amdgcn_s_sleep(1);
+                    if (*flag < it + 1 && lane == 0) lg_report(A.status, LG_STATUS_FRAME_HANDOVER_TIMEOUT);
 #pragma unroll 1
                     for (int b = j; b < T::L; b += NW - 1) {
                         const float4 f0 = sh.fk[b][0][lane], f1 = sh.fk[b][1][lane], f2 = sh.fk[b][2][lane], f3 = sh.fk[b][3][lane];
@@ -1296,7 +1309,7 @@ template <class T, bool NET, bool HF, int NW, bool SC = false> struct HelperWave
                     self_detect<T>(A, lds_tab, lane, wave, *sc);   // this wave's partner limb for all 64 lanes ...
                     if (wave == LG_STEP_WAVES - 1) self_detect<T>(A, lds_tab, lane, 0, *sc);      // ... and (the diagonal partner's wave) the base
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    if (lane == 0) sc->ready[wave] = it + 1;
+                    if (lane == 0 && A.debug_skip != 2) sc->ready[wave] = it + 1;
                 }
             }
         }
@@ -1930,6 +1943,8 @@ struct lg_sim {
     int            defer;            // lg_set_deferred_extras
     unsigned long long *d_prof;
     int            num_cus;
+    unsigned int  *h_status;         // host-mapped sticky status word (hipHostMalloc): the kernels OR LG_STATUS_* bits into it
+    int            spin_limit, debug_skip;
 };
 
 template <class T> static int check_topology(const lg_robot_model *m) {
@@ -2092,6 +2107,16 @@ static void fill_args(const lg_sim *s, KArgs &a, int64_t step) {
     a.actions_in = nullptr; a.env_ids = nullptr; a.count = 0; a.step = step; memset(&a.pol, 0, sizeof a.pol);
     a.penalised_mask = s->M.penalised_mask; a.termination_mask = s->M.termination_mask; a.done_counter = s->d_done; a.prof = s->d_prof;
     a.accum_alt = s->d_accum_alt; a.defer = s->defer; a.flush_parts = 0;
+    a.status = s->h_status; a.spin_limit = s->spin_limit; a.debug_skip = s->debug_skip;
+}
+// Entry check of every call on a handle: a status bit set by an earlier launch is an error from now on (sticky).
+static int status_error(const lg_sim *s) {
+    const unsigned int st = s->h_status ? __atomic_load_n(s->h_status, __ATOMIC_RELAXED) : 0u;
+    if (!st) return 0;
+    static thread_local char text[160];
+    snprintf(text, sizeof text, "0x%x%s%s", st, (st & LG_STATUS_FRAME_HANDOVER_TIMEOUT) ? " frame hand-over poll timed out" : "",
+             (st & LG_STATUS_SELF_COLLISION_TIMEOUT) ? " self-collision hand-over poll timed out" : "");
+    return fail(-20, "device status %s: an earlier launch on this handle ran with a missed LDS hand-over -- its physics is invalid (lg_clear_device_status() after re-initialising the state)", text);
 }
 template <class T> static int grid_for(int n_env_like) { return (n_env_like * T::K + LG_BLOCK - 1) / LG_BLOCK; }
 
@@ -2864,6 +2889,9 @@ int lg_create(const lg_params *params, const lg_robot_model *model, const float 
     if (!s) return fail(-5, "out of host memory");
     s->P = *params; s->M = *model; s->kind = kind; s->device = device_id; s->bound = false;
     s->has_net = actuator_weights != nullptr; s->d_weights = nullptr; s->d_limb_table = nullptr; s->d_done = nullptr; s->d_prof = nullptr; s->d_accum_alt = nullptr; s->defer = 0;
+    s->h_status = nullptr; s->spin_limit = 1 << 22; s->debug_skip = 0;
+    if (hipHostMalloc(reinterpret_cast<void **>(&s->h_status), sizeof(unsigned int), hipHostMallocMapped) != hipSuccess) { delete s; return fail(-10, "hipHostMalloc failed"); }
+    *s->h_status = 0u;
     if (hipMalloc(&s->d_accum_alt, (LG_NUM_REWARD_TERMS + 2) * sizeof(float)) != hipSuccess || hipMemset(s->d_accum_alt, 0, (LG_NUM_REWARD_TERMS + 2) * sizeof(float)) != hipSuccess) { delete s; return fail(-10, "hipMalloc failed"); }
     {   // [0] the workgroup ticket, [1 ..] one terrain-level partial sum per workgroup of k_step (at most 4 lanes per env)
         const size_t n_done = 1 + 2 * (((size_t)params->num_envs * 4 + LG_BLOCK - 1) / LG_BLOCK);      // (two slots of partials, by step parity)
@@ -2894,6 +2922,7 @@ void lg_destroy(lg_sim *s) {
     if (s->d_done) (void)hipFree(s->d_done);
     if (s->d_accum_alt) (void)hipFree(s->d_accum_alt);
     if (s->d_prof) (void)hipFree(s->d_prof);
+    if (s->h_status) (void)hipHostFree(s->h_status);
     delete s;
 }
 
@@ -2936,6 +2965,7 @@ static int waves_for(unsigned workgroups, int num_cus) { return workgroups <= (u
 
 int lg_step(lg_sim *s, const float *actions, int64_t common_step_counter, void *stream) {
     if (!s || !s->bound) return fail(-8, "lg_bind has not been called");
+    if (int rc = status_error(s)) return rc;
     if (!actions) return fail(-1, "null actions");
     if (common_step_counter < 0 && !s->B.step_counter) return fail(-9, "common_step_counter = -1 needs a step_counter buffer");
     KArgs a; fill_args(s, a, common_step_counter); a.actions_in = actions;
@@ -2965,6 +2995,7 @@ int lg_step(lg_sim *s, const float *actions, int64_t common_step_counter, void *
 int lg_step_policy(lg_sim *s, lg_policy *p, const float *obs, float *actions, float *mean, uint64_t seed, int32_t deterministic,
                    int64_t common_step_counter, void *stream) {
     if (!s || !s->bound) return fail(-8, "lg_bind has not been called");
+    if (int rc = status_error(s)) return rc;
     if (!p || !obs || !actions) return fail(-1, "null argument");
     if (common_step_counter < 0 && !s->B.step_counter) return fail(-9, "common_step_counter = -1 needs a step_counter buffer");
     const bool flat_actor = p->tiles[0] == 3 && p->tiles[1] == 8 && p->tiles[2] == 4 && p->tiles[3] == 2 && p->dims[4] == s->M.num_limbs * s->M.chain_len;
@@ -2985,6 +3016,7 @@ int lg_step_policy(lg_sim *s, lg_policy *p, const float *obs, float *actions, fl
 
 int lg_reset_idx(lg_sim *s, const int32_t *env_ids, int32_t count, int64_t common_step_counter, void *stream) {
     if (!s || !s->bound) return fail(-8, "lg_bind has not been called");
+    if (int rc = status_error(s)) return rc;
     if (count <= 0) return 0;
     if (!env_ids) return fail(-1, "null env_ids");
     KArgs a; fill_args(s, a, common_step_counter); a.env_ids = env_ids; a.count = count;
@@ -3003,6 +3035,26 @@ int lg_reset_idx(lg_sim *s, const int32_t *env_ids, int32_t count, int64_t commo
     return 0;
 }
 
+int lg_device_status(lg_sim *s, int32_t synchronize) {
+    if (!s) return fail(-1, "null argument");
+    if (synchronize) { HIP_TRY(hipSetDevice(s->device)); HIP_TRY(hipDeviceSynchronize()); }
+    const unsigned int st = __atomic_load_n(s->h_status, __ATOMIC_RELAXED);
+    if (st) (void)status_error(s);                           /* leaves the text in lg_last_error() */
+    return (int)(st & 0x7fffffffu);
+}
+int lg_clear_device_status(lg_sim *s) {
+    if (!s) return fail(-1, "null argument");
+    HIP_TRY(hipSetDevice(s->device)); HIP_TRY(hipDeviceSynchronize());
+    __atomic_store_n(s->h_status, 0u, __ATOMIC_RELAXED);
+    return 0;
+}
+int lg_debug_handover(lg_sim *s, int32_t skip, int32_t spin_limit) {
+    if (!s) return fail(-1, "null argument");
+    if (skip < 0 || skip > 2) return fail(-1, "skip must be 0 (off), 1 (frame flag) or 2 (self-collision flags)");
+    s->debug_skip = skip; s->spin_limit = spin_limit > 0 ? spin_limit : (1 << 22);
+    return 0;
+}
+
 int lg_set_deferred_extras(lg_sim *s, int32_t on) {
     if (!s) return fail(-1, "null argument");
     s->defer = on ? 1 : 0;
@@ -3011,6 +3063,7 @@ int lg_set_deferred_extras(lg_sim *s, int32_t on) {
 
 int lg_extras_flush(lg_sim *s, int64_t common_step_counter, void *stream) {
     if (!s || !s->bound) return fail(-8, "lg_bind has not been called");
+    if (int rc = status_error(s)) return rc;
     KArgs a; fill_args(s, a, common_step_counter);
     // the level partial sums exist when the step kernel runs with helper waves (lg_step's choice of waves per workgroup)
     const int nwg = s->kind == ROBOT_ANYMAL ? grid_for<AnymalTraits>(s->P.num_envs) : grid_for<CassieTraits>(s->P.num_envs);
@@ -3032,6 +3085,7 @@ int lg_actuator_forward(lg_sim *s, const float *pos_err, const float *vel, float
 
 int lg_physics_substep(lg_sim *s, const float *torques, int32_t write_contacts, void *stream) {
     if (!s || !s->bound) return fail(-8, "lg_bind has not been called");
+    if (int rc = status_error(s)) return rc;
     KArgs a; fill_args(s, a, 0);
     hipStream_t st = (hipStream_t)stream;
     const bool hf = s->P.terrain_type == LG_TERRAIN_HEIGHTFIELD;
@@ -3053,6 +3107,7 @@ int lg_physics_substep(lg_sim *s, const float *torques, int32_t write_contacts, 
 
 int lg_compute_observations_only(lg_sim *s, int64_t common_step_counter, void *stream) {
     if (!s || !s->bound) return fail(-8, "lg_bind has not been called");
+    if (int rc = status_error(s)) return rc;
     KArgs a; fill_args(s, a, common_step_counter);
     hipStream_t st = (hipStream_t)stream;
     if (s->kind == ROBOT_ANYMAL) hipLaunchKernelGGL((k_obs<AnymalTraits>), dim3(grid_for<AnymalTraits>(s->P.num_envs)), dim3(LG_BLOCK), 0, st, a);

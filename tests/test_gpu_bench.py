@@ -12,12 +12,12 @@ pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.realpath(__file__)))
 
 
-def _run(extra, env=None):
+def _run(extra, env=None, expect_rc=0):
     e = dict(os.environ, **(env or {}))
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
         e.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + extra, capture_output=True, text=True, timeout=420, env=e, cwd=REPO)
-    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.returncode == expect_rc, (r.returncode, r.stderr[-2000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]           # ONE JSON line, from rank 0 only
     return json.loads(lines[0])
@@ -57,9 +57,10 @@ def test_bench_lines_of_configs_3_and_5(task, envs, contact):
 @pytest.mark.parametrize("fault", ["raise:1", "hang:1"])
 def test_a_failing_ppo_leg_at_world_2_leaves_the_headline_line(fault):
     """The PPO leg holds the collectives of the N > 1 line; a rank that raises or stalls in it must not cost the headline: rank 0 still
-    prints its ONE line, with the error recorded in `ppo_training`, and every rank exits (no rank left inside a collective)."""
+    prints its ONE line, with the error recorded in `ppo_training`, and every rank exits (no rank left inside a collective) -- with a
+    NON-ZERO code (3), so the driver does not book a run whose training leg hung as a success."""
     out = _run(["--gpus", "2", "--steps", "40", "--warmup", "20", "--num-envs", "512", "--no-cpu-baseline", "--training-iters", "2"],
-               env={"LG_BENCH_BACKEND": "gloo", "LG_BENCH_PPO_FAULT": fault, "LG_BENCH_PPO_TIMEOUT_S": "20"})
+               env={"LG_BENCH_BACKEND": "gloo", "LG_BENCH_PPO_FAULT": fault, "LG_BENCH_PPO_TIMEOUT_S": "20"}, expect_rc=3)
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["gloo_ranks"] == 2
     assert "error" in out["ppo_training"]
 

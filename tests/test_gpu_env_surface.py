@@ -309,3 +309,38 @@ def test_rough_task_trains_on_the_wide_kernels_and_critic_pass_matches_torch(tmp
     assert float((got - want).abs().max()) < 1e-4 * max(1.0, float(want.abs().max()))
     c, _ = task_registry.get_cfgs("anymal_c_rough")
     c.env.num_envs = 4096
+
+
+@pytest.mark.parametrize("skip,bit", [(1, 0x1), (2, 0x2)])
+def test_missed_handover_is_a_sticky_error(skip, bit):
+    """A bounded LDS hand-over poll that runs out must not end in rc 0 with wrong physics: the kernel sets a sticky status bit
+    (host-mapped word), every later call on the handle fails with -20 until lg_clear_device_status().  lg_debug_handover()
+    withholds the flag (1: the rigid-body wave's frame flag, 2: the helpers' self-collision flags) with a short poll bound."""
+    import numpy as np
+    from tests.common import make_setup, grid_origins
+    from legged_games_gym_amd.device_sim import DeviceSim
+    N = 64
+    cfg, robot, p, names, model, w = make_setup("anymal_c_flat", N)
+    assert p.self_collision == 1
+    d = DeviceSim(p, model, robot, torch.device("cuda:0"), w)
+    d.buf["env_origins"].copy_(torch.from_numpy(grid_origins(N)))
+    ids = torch.arange(N, dtype=torch.int32)
+    d.reset_idx(ids, 0)
+    act = torch.zeros(N, 12, device="cuda")
+    d.step(act, 1)
+    assert d.sim.device_status(True) == 0
+    d.sim.debug_handover(skip, 64)
+    d.step(act, 2)                                        # launches fine: the status was clean when the call was made
+    st = d.sim.device_status(True)
+    assert st & bit, hex(st)
+    with pytest.raises(RuntimeError, match="hand-over"):
+        d.step(act, 3)
+    with pytest.raises(RuntimeError, match="-20"):
+        d.reset_idx(ids, 3)
+    d.sim.debug_handover(0, 0)
+    with pytest.raises(RuntimeError):                     # sticky: switching the hook off does not clear it
+        d.step(act, 3)
+    d.sim.clear_device_status()
+    d.reset_idx(ids, 3)
+    d.step(act, 4)
+    assert d.sim.device_status(True) == 0 and torch.isfinite(d.buf["root_states"]).all()
