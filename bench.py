@@ -54,6 +54,7 @@ def parse_args():
     ap.add_argument("--torch-policy", action="store_true", help="same as --policy torch")
     ap.add_argument("--graph-steps", type=int, default=20, help="policy steps captured per HIP-graph replay (clamped to a divisor of --steps and --warmup)")
     ap.add_argument("--no-fused-step", action="store_true", help="keep actor kernel and step kernel separate (lg_policy_act + lg_step)")
+    ap.add_argument("--no-rollout", action="store_true", help="one launch per policy step (lg_step_policy) instead of one per --graph-steps steps (lg_rollout_policy): the A/B of the multi-step kernel")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one captured HIP graph per step")
     ap.add_argument("--training-iters", type=int, default=-1, help="PPO iterations timed for the ppo_training object (0 = skip; -1 = 100 for anymal_c_flat, 20 otherwise)")
     ap.add_argument("--trimesh", action="store_true", help="keep the registered mesh_type 'trimesh' (vertical faces beyond slope_treshold) instead of BASELINE.json's height-field contact")
@@ -203,13 +204,22 @@ def worker(a):
         torch.cuda.synchronize()
 
     fused_step = False                                    # actor fused INTO the step kernel (lg_step_policy): flat actor only
+    rollout_kernel = False                                # ... and G steps per launch (lg_rollout_policy)
     G = 1
     if not a.no_graph:
         G = max(g for g in range(1, max(1, a.graph_steps) + 1) if a.steps % g == 0 and a.warmup % g == 0)
     with torch.inference_mode():
         if not use_torch and not a.no_fused_step:
             try:
-                one_step = env.make_graphed_policy_step(fused, steps_per_replay=G) if not a.no_graph else (lambda: env.step_policy(fused))
+                if not a.no_graph and not a.no_rollout and G > 1:
+                    try:                                       # G policy steps per LAUNCH (lg_rollout_policy), one HIP graph per segment
+                        one_step, _roll_storage = env.make_graphed_rollout(fused, G)
+                        rollout_kernel = True
+                    except RuntimeError as exc:
+                        if "multi-step rollout kernel" not in str(exc):
+                            raise
+                if not rollout_kernel:
+                    one_step = env.make_graphed_policy_step(fused, steps_per_replay=G) if not a.no_graph else (lambda: env.step_policy(fused))
                 if a.no_graph:
                     one_step()
                 fused_step = True
@@ -257,7 +267,7 @@ def worker(a):
         if fused_step and not a.no_graph:
             kern_ms_each = [1e3 * e / a.steps for e in evs]     # the timed graph IS G x k_step<..., POL>: same replays, same region
             kern_method = (f"HIP events on the launch stream around the {a.steps // G} graph replays of the timed region itself "
-                           f"(median of {repeats} regions; includes the ~1 us gaps between launches)")
+                           f"(median of {repeats} regions; includes the ~1 us gaps between launches" + (f" and, per {G}-step launch, the observation copy, the accumulator zeroing and the extras finisher" if rollout_kernel else "") + ")")
         else:
             KG = 20
             fixed_actions = (policy_act(env.obs_buf) if not fused_step else fused.act(env.obs_buf)).clone()
@@ -326,7 +336,7 @@ def worker(a):
         fl = flops_per_env_step(a.task, int(env.cfg.control.decimation))
         step_flops = fl["total"] - (0 if fused_step else fl["actor_mlp"])          # what the timed kernel computes
         tflops = step_flops * a.num_envs / (kern_ms * 1e-3) / 1e12
-        kname = {"anymal_c_flat": "k_step<AnymalTraits,NET,plane" + (",POL> (actor + step)" if fused_step else ">"),
+        kname = {"anymal_c_flat": "k_step<AnymalTraits,NET,plane" + ((",POL,ROLL> (actor + step, %d steps per launch)" % G) if rollout_kernel else ",POL> (actor + step)" if fused_step else ">"),
                  "cassie": "k_step<CassieTraits,PD,HF>"}.get(a.task, "k_step<AnymalTraits," + ("NET" if getattr(env.cfg.control, "use_actuator_network", False) else "PD") + ",HF>")
         out = {
             "metric": "env-steps/sec (whole node), ANYmal-C flat 4096 envs/GPU" if a.task == "anymal_c_flat" else f"env-steps/sec (whole node), {a.task}",
@@ -336,8 +346,10 @@ def worker(a):
             "config": {"workload": workload_text(a.task, env, pol, a.num_envs),
                        "envs_per_gpu": a.num_envs, "decimation": int(env.cfg.control.decimation), "sim_dt": float(env.sim_params.dt),
                        "parallelism": f"env-sharded x{world}", "state_finite": finite,
-                       "launch": ("eager" if a.no_graph else f"HIP graph of {G} policy steps per replay") + (": ONE kernel per step, actor fused into the step (lg_step_policy)" if fused_step else " (policy + lg_step)")
-                                 + ("" if a.no_graph or os.environ.get("LG_DEFER_EXTRAS", "1") == "0" else "; extras[\"episode\"] deferred to the next launch, one lg_extras_flush node per replay"),
+                       "launch": (f"lg_rollout_policy: ONE launch of k_step<...,POL,ROLL> per {G} policy steps (actor fused into the step, every workgroup walks through the {G} steps of its own 16 envs; "
+                                  f"per-step obs / actions / rewards / dones to rollout storage), replayed as a HIP graph with its observation copy, accumulator zeroing and extras finisher") if rollout_kernel else
+                                 (("eager" if a.no_graph else f"HIP graph of {G} policy steps per replay") + (": ONE kernel per step, actor fused into the step (lg_step_policy)" if fused_step else " (policy + lg_step)")
+                                  + ("" if a.no_graph or os.environ.get("LG_DEFER_EXTRAS", "1") == "0" else "; extras[\"episode\"] deferred to the next launch, one lg_extras_flush node per replay")),
                        "policy": "torch ops (hipBLASLt)" if use_torch else ("MFMA actor inside k_step (v_mfma_f32_16x16x4_f32, 4 waves)" if fused_step else "actor kernel lg_policy_act: k_policy_act_wide, 32 envs per workgroup, split-bf16 products (hi*hi + hi*lo + lo*hi, f32 accumulate) on v_mfma_f32_32x32x16_bf16")},
             "repeats": repeats,
             "timing": f"median of {repeats} timed regions of exactly {a.steps} steps each (a region shorter than {a.min_timed_ms:g} ms is repeated)" if repeats > 1 else f"one timed region of {a.steps} steps",

@@ -231,6 +231,31 @@ int  lg_policy_load_device(lg_policy *p, const float *const weights[4], const fl
 int  lg_step_policy(lg_sim *sim, lg_policy *p, const float *obs, float *actions, float *mean, uint64_t seed,
                     int32_t deterministic, int64_t common_step_counter, void *stream);
 
+/* A whole rollout segment in ONE launch: `steps` consecutive fused policy steps (actor + sampling + lg_step) -- what the caller's
+ * rollout loop does step by step ([EXTERNAL] rsl_rl OnPolicyRunner.learn: `for i in range(num_steps_per_env): actions =
+ * alg.act(obs, ...); obs, ..., = env.step(actions)`, entered from legged_gym/scripts/train.py:43), with identical results: the same
+ * state, observations, actions, rewards and dones as `steps` lg_step_policy calls, bit for bit.  Envs never interact, so every
+ * workgroup walks through the steps of its own envs without meeting the others at each step boundary: the launch ends with the
+ * slowest SUM over the steps instead of the sum of the slowest workgroups.  Per-step outputs go to caller-owned rollout storage:
+ * obs[steps + 1][N][num_obs] (obs[0] = the input of the first step, step t writes obs[t + 1]), actions / mean[steps][N][num_actions]
+ * (mean may be null), rew[steps][N], dones / time_outs[steps][N] (uint8).  The bound state buffers hold the state after the last
+ * step; extras["episode"] (episode_means) is that of the last step of the segment in which an env was reset (legged_robot.py:179-183);
+ * the device step counter advances by `steps`.  Compiled for the shape lg_step_policy is compiled for (48-128-64-32 actor,
+ * quadruped actuator-net kernel on the plane, no height measurements); -4 otherwise.  The first call on a handle allocates a small
+ * workspace (make it outside stream capture). */
+#define LG_MAX_ROLL_STEPS 256
+typedef struct {
+    int32_t  steps;
+    float   *obs;
+    float   *actions;
+    float   *mean;
+    float   *rew;
+    uint8_t *dones;
+    uint8_t *time_outs;
+} lg_rollout_buffers;
+int  lg_rollout_policy(lg_sim *sim, lg_policy *p, const lg_rollout_buffers *out, uint64_t seed, int32_t deterministic,
+                       int64_t common_step_counter, void *stream);
+
 /* GAE(gamma, lambda) scan over a rollout, one thread per env (rsl_rl RolloutStorage.compute_returns, [EXTERNAL]; hyper-
  * parameters legged_robot_config.py:222-223).  rewards, values, returns, advantages: float [T, N]; dones: uint8 [T, N];
  * last_values: float [N].  returns[t] = A_t + V_t with A_t = delta_t + gamma lam (1 - done_t) A_{t+1}; advantages = returns -

@@ -87,6 +87,14 @@ class lg_params(C.Structure):
 _PF, _PU8, _PI64, _PI32, _PI16 = C.POINTER(f32), C.POINTER(u8), C.POINTER(i64), C.POINTER(i32), C.POINTER(i16)
 
 
+class lg_rollout_buffers(C.Structure):
+    """Rollout storage of ``lg_rollout_policy`` (include/legged_hip.h): [steps(+1)][N][...] device arrays owned by the caller."""
+    _fields_ = [("steps", i32), ("obs", _PF), ("actions", _PF), ("mean", _PF), ("rew", _PF), ("dones", _PU8), ("time_outs", _PU8)]
+
+
+LG_MAX_ROLL_STEPS = 256
+
+
 class lg_buffers(C.Structure):
     _fields_ = [
         ("root_states", _PF), ("dof_state", _PF), ("contact_forces", _PF), ("obs_buf", _PF), ("rew_buf", _PF),
@@ -247,6 +255,8 @@ def bind_prototypes(lib, prefix: str):
         lib.lg_policy_load_device.restype = C.c_int
         lib.lg_step_policy.argtypes = [vp, vp, vp, vp, vp, u64, i32, i64, vp]
         lib.lg_step_policy.restype = C.c_int
+        lib.lg_rollout_policy.argtypes = [vp, vp, C.POINTER(lg_rollout_buffers), u64, i32, i64, vp]
+        lib.lg_rollout_policy.restype = C.c_int
         lib.lg_gae_returns.argtypes = [vp, vp, vp, vp, C.c_float, C.c_float, vp, vp, i32, i32, vp]
         lib.lg_gae_returns.restype = C.c_int
         lib.lg_ppo_loss.argtypes = [vp] * 11 + [C.c_float, C.c_float, C.c_float, i32, vp, vp, vp, vp, i32, i32, vp]
@@ -292,7 +302,7 @@ EXPORTED_SYMBOLS = ["lg_create", "lg_destroy", "lg_bind", "lg_step", "lg_reset_i
                     "lg_abi_version", "lg_sizeof", "lg_set_obs_buffer", "lg_policy_create", "lg_policy_destroy", "lg_policy_act",
                     "lg_step_policy", "lg_gae_returns", "lg_ppo_loss", "lg_policy_load_device", "lg_mlp_forward",
                     "lg_mlp_workspace_bytes", "lg_mlp_backward", "lg_mlp_wide_workspace_bytes", "lg_mlp_wide_forward", "lg_mlp_wide_backward", "lg_mlp_wide_set_precision", "lg_adam_step", "lg_rollout_record", "lg_mlp_trace", "lg_ppo_minibatch", "lg_set_deferred_extras", "lg_extras_flush",
-                    "lg_device_status", "lg_clear_device_status", "lg_debug_handover"]
+                    "lg_device_status", "lg_clear_device_status", "lg_debug_handover", "lg_rollout_policy"]
 
 
 def load_library():
@@ -351,6 +361,14 @@ class Sim:
                     common_step_counter: int, stream: int = 0):
         self._check(self.lib.lg_step_policy(self.handle, policy_handle, obs_ptr, actions_ptr, mean_ptr, int(seed), int(bool(deterministic)),
                                             int(common_step_counter), stream))
+
+    def rollout_policy(self, policy_handle, steps: int, obs_ptr: int, actions_ptr: int, mean_ptr, rew_ptr: int, dones_ptr: int, time_outs_ptr: int,
+                       seed: int, deterministic: bool, common_step_counter: int, stream: int = 0):
+        r = lg_rollout_buffers()
+        r.steps = int(steps)
+        for name, ptr in (("obs", obs_ptr), ("actions", actions_ptr), ("mean", mean_ptr), ("rew", rew_ptr), ("dones", dones_ptr), ("time_outs", time_outs_ptr)):
+            setattr(r, name, C.cast(C.c_void_p(ptr or 0), dict(lg_rollout_buffers._fields_)[name]))
+        self._check(self.lib.lg_rollout_policy(self.handle, policy_handle, C.byref(r), int(seed), int(bool(deterministic)), int(common_step_counter), stream))
 
     def set_deferred_extras(self, on: bool):
         self._check(self.lib.lg_set_deferred_extras(self.handle, int(bool(on))))

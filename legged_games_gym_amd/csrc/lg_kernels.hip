@@ -68,6 +68,17 @@ enum { J_POS = 0, J_ROT = 3, J_AXIS = 12, J_MASS = 15, J_COM = 16, J_INERTIA = 1
 
 struct BaseTab { float mass, com[3], inertia[6]; float pts[LG_MAX_BASE_POINTS][4]; int32_t num_pts; float mass_robot; };   // num_pts <= K; mass_robot: nominal total mass
 
+// lg_rollout_policy: k_step<..., ROLL> runs `steps` consecutive policy steps in ONE launch (each workgroup walks through the steps of its
+// own 16 envs without waiting for the other 255 at every step boundary); per-step outputs go to [t]-indexed rollout storage.
+struct RollArgs {
+    int      steps;
+    float   *obs;              // [steps + 1][N][num_obs]: obs[0] is the input of step 0, step t writes obs[t + 1]
+    float   *actions, *mean;   // [steps][N][num_actions] (mean may be null)
+    float   *rew;              // [steps][N]
+    uint8_t *done, *time_outs; // [steps][N]
+    float   *extras;           // [steps][LG_NUM_REWARD_TERMS + 2] episode accumulators per step (zeroed before the launch; k_roll_finish publishes)
+};
+
 struct KArgs {                 // passed by value: lives in the kernarg segment -> scalar loads
     lg_params  P;
     lg_buffers B;
@@ -90,6 +101,7 @@ struct KArgs {                 // passed by value: lives in the kernarg segment 
     unsigned int *status;         // sticky device status word (host-mapped): LG_STATUS_* bits, see lg_device_status()
     int   spin_limit;             // bound of the LDS hand-over polls (s_sleep rounds); lg_debug_handover() shrinks it
     int   debug_skip;             // test hook: 1 = the rigid-body wave withholds the frame hand-over flag, 2 = the helpers withhold the self-collision flags
+    RollArgs roll;                // k_step<..., ROLL> only
 };
 
 // A hand-over poll that ran out must not pass silently (rc 0 with wrong physics is the worst failure this library can have): the
@@ -102,7 +114,8 @@ LG_DEV void lg_report(unsigned int *status, unsigned int bit) {
 // ------------------------------------------------------------------ section profiler (debug builds: -DLG_PROFILE)
 #define LG_NPROF 20
 #define LG_NPROF_BLOCKS 1024
-#define LG_NPROF_TOTAL (LG_NPROF + LG_NPROF_BLOCKS * 40)
+#define LG_NPROF_ROLL 33             // rollout kernel (profile builds): wall-clock stamps [step boundary 0 .. 32][workgroup]
+#define LG_NPROF_TOTAL (LG_NPROF + LG_NPROF_BLOCKS * 40 + LG_NPROF_ROLL * LG_NPROF_BLOCKS)
 #ifdef LG_PROFILE
 // lane 0 of each workgroup accumulates s_memtime deltas per section in LDS and adds them to A.prof at the end.
 // idx < 0 starts the clock; slot 14 = whole kernel (s_memtime), slot 15 = whole kernel on the 100 MHz wall clock.
@@ -1055,7 +1068,8 @@ template <class T>
 LG_DEV void write_observations(const KArgs &A, int e, int k, bool live, int64_t step, const float *root, const float (&q)[T::L],
                                const float (&qd)[T::L], const float (&act)[T::L], const float *tab, V3 blv, V3 bav, V3 pg,
                                const float (&cmd)[4], bool heights_from_buffer /* k_obs: also the height block, from measured_heights */,
-                               const ResetRand<T> *rr = nullptr, int lane = 0) {
+                               const ResetRand<T> *rr = nullptr, int lane = 0, float *obs_out = nullptr /* instead of B.obs_buf (rollout storage) */,
+                               float *lds_row = nullptr /* rollout kernel: LDS copy of this env's row, the next step's actor input */) {
     constexpr int K = T::K, L = T::L;
     const lg_params &P = A.P;
     float head[12] = {blv.x * P.obs_scale_lin_vel, blv.y * P.obs_scale_lin_vel, blv.z * P.obs_scale_lin_vel,
@@ -1075,7 +1089,7 @@ LG_DEV void write_observations(const KArgs &A, int e, int k, bool live, int64_t 
         val[2][j] = qd[j] * P.obs_scale_dof_vel; nz[2][j] = P.noise_dof_vel;
         val[3][j] = act[j]; nz[3][j] = 0.0f;
     }
-    float *obs = A.B.obs_buf + (size_t)e * P.num_obs;
+    float *obs = (obs_out ? obs_out : A.B.obs_buf) + (size_t)e * P.num_obs;
 #pragma unroll
     for (int g = 0; g < 4; g++) {
         float u[4], u2[4];
@@ -1096,6 +1110,7 @@ LG_DEV void write_observations(const KArgs &A, int e, int k, bool live, int64_t 
             }
             o = fminf(fmaxf(o, -P.clip_observations), P.clip_observations);
             if (live) obs[g * 12 + k * L + j] = o;
+            if (lds_row) lds_row[g * 12 + k * L + j] = o;
         }
     }
     if (P.measure_heights && heights_from_buffer) {
@@ -1255,7 +1270,8 @@ template <class T, bool NET, bool HF, int NW, bool SC = false> struct HelperWave
                                                                  // wave w takes bodies w-1, w-1 + (NW-1), ...
     static LG_DEV void run(const KArgs &A, int wave, int lane, int e, int k, int d0, bool live, int64_t step, const float *tab,
                            float2 (*lds_x)[LG_BLOCK], float (*lds_tau)[LG_BLOCK], StepSharedT<OFF, T::L> &sh, SelfLds<T> *sc = nullptr,
-                           const float *lds_tab = nullptr, ResetRand<T> *reset_rand = nullptr, int *s_last = nullptr, float4 (*hnoise)[LG_BLOCK] = nullptr) {
+                           const float *lds_tab = nullptr, ResetRand<T> *reset_rand = nullptr, int *s_last = nullptr, float4 (*hnoise)[LG_BLOCK] = nullptr,
+                           int sub0 = 0 /* sub-steps before this policy step in the launch (rollout kernel) */, float *roll_accum = nullptr /* rollout kernel: this step's episode accumulators */) {
         const lg_buffers &B = A.B;
         const lg_params &P = A.P;
         const int j = wave - 1;
@@ -1288,8 +1304,8 @@ template <class T, bool NET, bool HF, int NW, bool SC = false> struct HelperWave
                     volatile int *flag = &sh.fk_ready;
                     // bounded: ~0.3 s at most, then go on with whatever is in LDS (wrong numbers beat a hung CU; the rigid-body
                     // wave publishes the flag unconditionally every sub-step, so the bound is never reached in a correct run)
-                    for (int spin = 0; *flag < it + 1 && spin < A.spin_limit; spin++) __builtin_amdgcn_s_sleep(1);
-                    if (*flag < it + 1 && lane == 0) lg_report(A.status, LG_STATUS_FRAME_HANDOVER_TIMEOUT);
+                    for (int spin = 0; *flag < sub0 + it + 1 && spin < A.spin_limit; spin++) __builtin_amdgcn_s_sleep(1);
+                    if (*flag < sub0 + it + 1 && lane == 0) lg_report(A.status, LG_STATUS_FRAME_HANDOVER_TIMEOUT);
 #pragma unroll 1
                     for (int b = j; b < T::L; b += NW - 1) {
                         const float4 f0 = sh.fk[b][0][lane], f1 = sh.fk[b][1][lane], f2 = sh.fk[b][2][lane], f3 = sh.fk[b][3][lane];
@@ -1309,7 +1325,7 @@ template <class T, bool NET, bool HF, int NW, bool SC = false> struct HelperWave
                     self_detect<T>(A, lds_tab, lane, wave, *sc);   // this wave's partner limb for all 64 lanes ...
                     if (wave == LG_STEP_WAVES - 1) self_detect<T>(A, lds_tab, lane, 0, *sc);      // ... and (the diagonal partner's wave) the base
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    if (lane == 0 && A.debug_skip != 2) sc->ready[wave] = it + 1;
+                    if (lane == 0 && A.debug_skip != 2) sc->ready[wave] = sub0 + it + 1;
                 }
             }
         }
@@ -1357,7 +1373,9 @@ template <class T, bool NET, bool HF, int NW, bool SC = false> struct HelperWave
         if (P.measure_heights) hc.draw_noise(P, e, k + T::K * wave, step, un);
         __syncthreads();                                           // P3: reset flags / post-reset root z / reward terms published
         if (wave == 1) {
-            es.template update<T::K>(A, e, lane, sh, keeper, accum_slot(A, step));
+            es.template update<T::K>(A, e, lane, sh, keeper, roll_accum ? roll_accum : accum_slot(A, step));
+            if (roll_accum) { /* rollout kernel: no ticket, no step counter -- k_roll_finish publishes after the launch */ }
+            else {
             if (P.terrain_curriculum && A.B.terrain_levels) {      // (wave-uniform) this workgroup's share of the mean terrain level: the reset
                 // lanes' new levels were stored and drained by the rigid-body wave before P3; read past this CU's L1, which may hold the old line
                 int lv = keeper ? __hip_atomic_load(A.B.terrain_levels + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
@@ -1386,6 +1404,7 @@ template <class T, bool NET, bool HF, int NW, bool SC = false> struct HelperWave
                 *s_last = last;
             }
             }
+            }
         }
         if (P.measure_heights) hc.write_obs(A, e, k + T::K * wave, live, step, sh.root_z[lane], un);
         if (NET) {                                                 // reset envs: actuator state zeroed (anymal.py:59-60), over the early write-back above
@@ -1410,9 +1429,10 @@ template <bool SC, class T> struct SelfStore { char unused; LG_DEV SelfLds<T> *g
 template <class T> struct SelfStore<true, T> { SelfLds<T> lds; LG_DEV SelfLds<T> *get() { return &lds; } };
 
 // SC: self-collision between the robot's own links (asset.self_collisions = 0; compiled for the quadruped layouts)
-template <class T, bool NET, bool HF, bool POL = false, int NW = LG_STEP_WAVES, bool SC = false>
+template <class T, bool NET, bool HF, bool POL = false, int NW = LG_STEP_WAVES, bool SC = false, bool ROLL = false>
 __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
     static_assert(!NET || (NW == LG_STEP_WAVES && 1 + T::L == NW), "one actuator wave per joint of the limb");
+    static_assert(!ROLL || (POL && !HF), "the multi-step rollout kernel is the fused-actor kernel on the plane");
     static_assert(!POL || (NET && NW == LG_POLICY_WAVES && T::K * T::L <= 16), "fused policy needs the four-wave actuator-net kernel");
     constexpr int K = T::K, L = T::L, ND = K * L, NREP = T::NREP;
     const lg_params &P = A.P;
@@ -1428,6 +1448,7 @@ __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
     __shared__ int s_last;
     __shared__ float4 pol_xa[POL ? 4 : 1][64], pol_xb[POL ? 8 : 1][64], pol_xy[1][64];
     __shared__ float lds_act[POL ? 16 : 1][16];                 // sampled actions [action][env in block]
+    __shared__ float lds_obs[ROLL ? 16 : 1][48];                // rollout kernel: the observations a step leaves for the next step's actor
     LG_PROF_BEGIN();
     if (threadIdx.x == 0) sh.fk_ready = 0;                      // published before the first use by stage_limb_table's barrier
     if constexpr (SC) {
@@ -1445,14 +1466,42 @@ __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
     if (!live) e = N - 1;
     const float *tab = lds_tab + k * Tab<T>::STRIDE;
     const int d0 = e * ND + k * L;                                // first dof of this lane
-    const int64_t step = A.step >= 0 ? A.step : B.step_counter[0] + 1;   // -1: self-advancing (HIP-graph replay)
+    const int64_t step0 = A.step >= 0 ? A.step : B.step_counter[0] + 1;   // -1: self-advancing (HIP-graph replay)
+    // ROLL: `roll.steps` policy steps in this launch.  Every step is the single-step kernel's body on the same state buffers; the
+    // workgroup's own stores are ordered before the next step's loads by the barrier that ends the step (workgroup-scope release /
+    // acquire; all of an env's data stays inside its workgroup), per-step outputs go to the [t] slice of the rollout storage.
+    const int e_wg = e, k_wg = k;
+    auto one_step = [&](const int rt) {
+    // ROLL: the loop must not become one giant live range -- without this, loop-invariant code motion hoists the limb-table reads, the
+    // per-env constants and the actuator weights of EVERY section above the loop and spills ~260 registers per lane.  Laundering the
+    // lane's (env, limb) indices through an empty asm makes every address of the step depend on a per-iteration value.
+    // (the thread index itself: the actor's per-lane weight addresses were otherwise computed once above the loop, spilled, and reloaded
+    // from scratch one by one in front of the loads that need them -- ~3 us per step)
+    int tix = threadIdx.x;
+    if constexpr (ROLL) asm volatile("" : "+v"(tix));
+    const int wave = tix / LG_BLOCK, lane = tix % LG_BLOCK;
+    int e = e_wg;
+    const int k = ROLL ? (blockIdx.x * LG_BLOCK + lane) % K : k_wg;
+    if constexpr (ROLL) { e = (blockIdx.x * LG_BLOCK + lane) / K; if (e >= N) e = N - 1; }
+    const float *tab = lds_tab + k * Tab<T>::STRIDE;
+    const int d0 = e * ND + k * L;
+    const int64_t step = step0 + rt;
+    const int sub0 = ROLL ? rt * P.decimation : 0;
+    float *const roll_accum = ROLL ? A.roll.extras + (size_t)rt * (LG_NUM_REWARD_TERMS + 2) : nullptr;
+    float *const roll_obs_out = ROLL ? A.roll.obs + (size_t)(rt + 1) * N * P.num_obs : nullptr;
 
     if (POL) {
-        policy_forward<3, 8, 4, 2>(A.pol, pol_xa, pol_xb, pol_xy, blockIdx.x, wave, lane, step, lds_act);
+        if (ROLL) {
+            PolicyArgs pa = A.pol;
+            pa.obs = A.roll.obs + (size_t)rt * N * P.num_obs;
+            pa.actions = A.roll.actions + (size_t)rt * N * ND;
+            pa.mean = A.roll.mean ? A.roll.mean + (size_t)rt * N * ND : nullptr;
+            policy_forward<3, 8, 4, 2>(pa, pol_xa, pol_xb, pol_xy, blockIdx.x, wave, lane, step, lds_act, rt > 0 ? lds_obs : nullptr);
+        } else policy_forward<3, 8, 4, 2>(A.pol, pol_xa, pol_xb, pol_xy, blockIdx.x, wave, lane, step, lds_act);
         __syncthreads();
     }
     if (wave > 0) {
-        HelperWave<T, NET, HF, NW, SC>::run(A, wave, lane, e, k, d0, live, step, tab, lds_x, lds_tau, sh, sc_store.get(), lds_tab, &reset_rand, &s_last, hnoise);
+        HelperWave<T, NET, HF, NW, SC>::run(A, wave, lane, e, k, d0, live, step, tab, lds_x, lds_tau, sh, sc_store.get(), lds_tab, &reset_rand, &s_last, hnoise, sub0, roll_accum);
     } else {
     // ---- load persistent state (read once per env-step)
     float root[13], q[L], qd[L], act[L], tau[L];
@@ -1502,7 +1551,7 @@ __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
                     for (int j = 0; j < L; j++) tau[j] = lds_tau[j][lane];
                 }
             };
-            physics_substep<T, HF, decltype(join), OFF, SC>(A, tab, k, root, q, qd, tau, base_mass, mu, Frep, Fbase, join, sh.bt, sh.fk, &sh.fk_ready, it + 1,
+            physics_substep<T, HF, decltype(join), OFF, SC>(A, tab, k, root, q, qd, tau, base_mass, mu, Frep, Fbase, join, sh.bt, sh.fk, &sh.fk_ready, sub0 + it + 1,
                                                             sc_store.get(), it == P.decimation - 1, SC && NW == LG_STEP_WAVES);
         } else {
             physics_substep<T, HF, NoWait, false, SC>(A, tab, k, root, q, qd, tau, base_mass, mu, Frep, Fbase, NoWait(), nullptr, nullptr, nullptr, 0,
@@ -1676,7 +1725,7 @@ __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
     { int nr = 0; for (int i = 0; i < LG_BLOCK; i += K) nr += sh.rst[i]; LG_PROF_NOTE(18, (unsigned long long)nr); }
 #endif
     // compute_observations :130 (stale base-frame quantities for reset envs, as in the reference)
-    write_observations<T>(A, e, k, live, step, root, q, qd, act, tab, blv, bav, pg, cmd, false, NW > 1 ? &reset_rand : nullptr, lane);
+    write_observations<T>(A, e, k, live, step, root, q, qd, act, tab, blv, bav, pg, cmd, false, NW > 1 ? &reset_rand : nullptr, lane, roll_obs_out, ROLL ? lds_obs[lane / K] : nullptr);
     if (P.measure_heights) {
         if (NW > 1) {
             float un[HeightCrew<T, NW>::NCH][4];
@@ -1713,6 +1762,11 @@ __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
             B.reset_buf[e] = (uint8_t)reset;
             B.time_out_buf[e] = (uint8_t)time_out;
             B.episode_length_buf[e] = ep_len;
+            if (ROLL) {
+                A.roll.rew[(size_t)rt * N + e] = rew;
+                A.roll.done[(size_t)rt * N + e] = (uint8_t)reset;
+                A.roll.time_outs[(size_t)rt * N + e] = (uint8_t)time_out;
+            }
         }
     }
     // ---- the workgroup that finishes last turns the accumulated sums into extras["episode"] (was a second launch).
@@ -1720,6 +1774,27 @@ __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
     // agent-scope release fence per workgroup measured +6 us); the ticket is taken after this wave's own memory operations
     // have drained (s_waitcnt vmcnt(0)), and the finisher reads with device-scope (L1-bypassing) loads.
     }   // physics wave
+    };  // one_step
+    if constexpr (ROLL) {
+#ifdef LG_PROFILE
+        if (threadIdx.x == 0 && A.prof && blockIdx.x < LG_NPROF_BLOCKS) A.prof[LG_NPROF + LG_NPROF_BLOCKS * 40 + blockIdx.x] = wall_clock64();
+#endif
+#pragma unroll 1
+        for (int rt = 0; rt < A.roll.steps; rt++) {
+            one_step(rt);
+            // Step boundary inside the launch.  What the next step reads of this step's GLOBAL stores it reads in the wave that stored it
+            // (state, actuator rows, episode sums: same wave instruction stream, in order) -- the one cross-wave item, the observations the
+            // actor starts from, goes through lds_obs.  So the boundary is an LDS release + barrier; the stores need not be drained (a full
+            // __syncthreads() with its vmcnt(0) cost every workgroup ~2 us per step).
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef LG_PROFILE
+            if (threadIdx.x == 0 && A.prof && blockIdx.x < LG_NPROF_BLOCKS && rt + 1 < LG_NPROF_ROLL)
+                A.prof[LG_NPROF + LG_NPROF_BLOCKS * 40 + (size_t)(rt + 1) * LG_NPROF_BLOCKS + blockIdx.x] = wall_clock64();
+#endif
+        }
+        return;                    // extras["episode"] and the step counter: k_roll_finish, behind this launch
+    } else one_step(0);
+    const int64_t step = step0;
     LG_PROF(PF_POST);
     if (NW == 1 && !A.defer) {                                     // no helper wave: ticket at the end, behind this wave's own memory operations
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1814,6 +1889,24 @@ __global__ void __launch_bounds__(64) k_extras(const KArgs A) {        // behind
     const int64_t last = A.step >= 0 ? A.step : (A.B.step_counter ? A.B.step_counter[0] : 0);
     finish_extras(A, threadIdx.x, A.step, false, A.B.extras_accum, A.flush_parts > 0 ? level_parts_slot(A, last, A.flush_parts) : nullptr, A.flush_parts);
     if (A.accum_alt) finish_extras(A, threadIdx.x, A.step, false, A.accum_alt, nullptr, 0, false);
+}
+
+// ------------------------------------------------------------------ lg_rollout_policy: around the multi-step launch
+__global__ void __launch_bounds__(256) k_roll_zero(float *extras, int n) {      // (a kernel, not a memset node: small memset nodes inside replayed HIP graphs proved unreliable)
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) extras[i] = 0.0f;
+}
+__global__ void __launch_bounds__(64) k_roll_finish(const KArgs A) {
+    // extras["episode"] (legged_robot.py:179-188): the sums of the LAST step of the launch in which any env was reset (the dictionary
+    // stays stale otherwise, quirk Q4); the device step counter moves to the last executed step.
+    const lg_params &P = A.P;
+    const int t = threadIdx.x, R = P.num_reward_slots, stride = LG_NUM_REWARD_TERMS + 2;
+    const int64_t step0 = A.step >= 0 ? A.step : (A.B.step_counter ? A.B.step_counter[0] + 1 : 0);
+    int last = -1;
+    for (int s = A.roll.steps - 1; s >= 0 && last < 0; s--) if (A.roll.extras[(size_t)s * stride + R] > 0.0f) last = s;
+    if (last >= 0 && t < R) A.B.episode_means[t] = A.roll.extras[(size_t)last * stride + t] / A.roll.extras[(size_t)last * stride + R] / P.max_episode_length_s;
+    __builtin_amdgcn_s_waitcnt(0);
+    if (t == 0 && A.B.step_counter) A.B.step_counter[0] = step0 + A.roll.steps - 1;
 }
 
 // ------------------------------------------------------------------ sub-path kernels (parity tests drive these)
@@ -1943,6 +2036,7 @@ struct lg_sim {
     int            defer;            // lg_set_deferred_extras
     unsigned long long *d_prof;
     int            num_cus;
+    float         *d_roll_extras;    // lg_rollout_policy: [LG_MAX_ROLL_STEPS][LG_NUM_REWARD_TERMS + 2] per-step episode accumulators
     unsigned int  *h_status;         // host-mapped sticky status word (hipHostMalloc): the kernels OR LG_STATUS_* bits into it
     int            spin_limit, debug_skip;
 };
@@ -2108,6 +2202,7 @@ static void fill_args(const lg_sim *s, KArgs &a, int64_t step) {
     a.penalised_mask = s->M.penalised_mask; a.termination_mask = s->M.termination_mask; a.done_counter = s->d_done; a.prof = s->d_prof;
     a.accum_alt = s->d_accum_alt; a.defer = s->defer; a.flush_parts = 0;
     a.status = s->h_status; a.spin_limit = s->spin_limit; a.debug_skip = s->debug_skip;
+    memset(&a.roll, 0, sizeof a.roll);
 }
 // Entry check of every call on a handle: a status bit set by an earlier launch is an error from now on (sticky).
 static int status_error(const lg_sim *s) {
@@ -2863,6 +2958,13 @@ int lg_debug_profile_blocks(lg_sim *s, unsigned long long *out, int blocks) {
         if (hipMemcpy(out + (size_t)b * 20, s->d_prof + LG_NPROF + (size_t)b * 40 + 20, sizeof(unsigned long long) * 20, hipMemcpyDeviceToHost) != hipSuccess) return -2;
     return 0;
 }
+// rollout kernel, last launch: out[LG_NPROF_ROLL][LG_NPROF_BLOCKS] wall-clock stamps (100 MHz) of every workgroup at every step boundary
+int lg_debug_profile_roll(lg_sim *s, unsigned long long *out) {
+    if (!s || !s->d_prof) return -1;
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    if (hipMemcpy(out, s->d_prof + LG_NPROF + (size_t)LG_NPROF_BLOCKS * 40, sizeof(unsigned long long) * LG_NPROF_ROLL * LG_NPROF_BLOCKS, hipMemcpyDeviceToHost) != hipSuccess) return -2;
+    return 0;
+}
 #endif
 int lg_sizeof(int which) {
     switch (which) { case 0: return (int)sizeof(lg_params); case 1: return (int)sizeof(lg_robot_model);
@@ -2889,7 +2991,7 @@ int lg_create(const lg_params *params, const lg_robot_model *model, const float 
     if (!s) return fail(-5, "out of host memory");
     s->P = *params; s->M = *model; s->kind = kind; s->device = device_id; s->bound = false;
     s->has_net = actuator_weights != nullptr; s->d_weights = nullptr; s->d_limb_table = nullptr; s->d_done = nullptr; s->d_prof = nullptr; s->d_accum_alt = nullptr; s->defer = 0;
-    s->h_status = nullptr; s->spin_limit = 1 << 22; s->debug_skip = 0;
+    s->h_status = nullptr; s->spin_limit = 1 << 22; s->debug_skip = 0; s->d_roll_extras = nullptr;
     if (hipHostMalloc(reinterpret_cast<void **>(&s->h_status), sizeof(unsigned int), hipHostMallocMapped) != hipSuccess) { delete s; return fail(-10, "hipHostMalloc failed"); }
     *s->h_status = 0u;
     if (hipMalloc(&s->d_accum_alt, (LG_NUM_REWARD_TERMS + 2) * sizeof(float)) != hipSuccess || hipMemset(s->d_accum_alt, 0, (LG_NUM_REWARD_TERMS + 2) * sizeof(float)) != hipSuccess) { delete s; return fail(-10, "hipMalloc failed"); }
@@ -2923,6 +3025,7 @@ void lg_destroy(lg_sim *s) {
     if (s->d_accum_alt) (void)hipFree(s->d_accum_alt);
     if (s->d_prof) (void)hipFree(s->d_prof);
     if (s->h_status) (void)hipHostFree(s->h_status);
+    if (s->d_roll_extras) (void)hipFree(s->d_roll_extras);
     delete s;
 }
 
@@ -3010,6 +3113,40 @@ int lg_step_policy(lg_sim *s, lg_policy *p, const float *obs, float *actions, fl
     else
         hipLaunchKernelGGL((k_step<AnymalTraits, true, false, true>), dim3(grid_for<AnymalTraits>(s->P.num_envs)), dim3(LG_STEP_WAVES * LG_BLOCK),
                            0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int lg_rollout_policy(lg_sim *s, lg_policy *p, const lg_rollout_buffers *r, uint64_t seed, int32_t deterministic, int64_t common_step_counter, void *stream) {
+    if (!s || !s->bound) return fail(-8, "lg_bind has not been called");
+    if (int rc = status_error(s)) return rc;
+    if (!p || !r || !r->obs || !r->actions || !r->rew || !r->dones || !r->time_outs) return fail(-1, "null argument");
+    if (r->steps < 1 || r->steps > LG_MAX_ROLL_STEPS) return fail(-1, "steps must be in [1, LG_MAX_ROLL_STEPS]");
+    if (common_step_counter < 0 && !s->B.step_counter) return fail(-9, "common_step_counter = -1 needs a step_counter buffer");
+    const bool flat_actor = p->tiles[0] == 3 && p->tiles[1] == 8 && p->tiles[2] == 4 && p->tiles[3] == 2 && p->dims[4] == s->M.num_limbs * s->M.chain_len;
+    if (!(s->kind == ROBOT_ANYMAL && s->P.control_type == LG_CTRL_ACTUATOR_NET && s->P.terrain_type != LG_TERRAIN_HEIGHTFIELD && flat_actor
+          && p->dims[0] == s->P.num_obs && !s->P.measure_heights))
+        return fail(-4, "the multi-step rollout kernel is compiled for the 48-128-64-32 actor on the quadruped actuator-net plane kernel; use lg_step_policy / lg_policy_act + lg_step");
+    hipStream_t st = (hipStream_t)stream;
+    const int stride = LG_NUM_REWARD_TERMS + 2;
+    if (!s->d_roll_extras) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(st, &cap);
+        if (cap != hipStreamCaptureStatusNone) return fail(-9, "first lg_rollout_policy call on a handle allocates its workspace: make one call outside stream capture");
+        HIP_TRY(hipSetDevice(s->device));
+        if (hipMalloc(&s->d_roll_extras, sizeof(float) * LG_MAX_ROLL_STEPS * stride) != hipSuccess) return fail(-10, "hipMalloc failed");
+    }
+    KArgs a; fill_args(s, a, common_step_counter); a.actions_in = nullptr; a.defer = 0;
+    fill_policy_args(p, a.pol, r->obs, r->actions, r->mean, s->P.num_envs, seed, common_step_counter, s->B.step_counter, deterministic);
+    a.roll.steps = r->steps; a.roll.obs = r->obs; a.roll.actions = r->actions; a.roll.mean = r->mean; a.roll.rew = r->rew;
+    a.roll.done = r->dones; a.roll.time_outs = r->time_outs; a.roll.extras = s->d_roll_extras;
+    const int n = r->steps * stride;
+    hipLaunchKernelGGL(k_roll_zero, dim3((n + 255) / 256), dim3(256), 0, st, s->d_roll_extras, n);
+    if (s->P.self_collision)
+        hipLaunchKernelGGL((k_step<AnymalTraits, true, false, true, 4, true, true>), dim3(grid_for<AnymalTraits>(s->P.num_envs)), dim3(LG_STEP_WAVES * LG_BLOCK), 0, st, a);
+    else
+        hipLaunchKernelGGL((k_step<AnymalTraits, true, false, true, 4, false, true>), dim3(grid_for<AnymalTraits>(s->P.num_envs)), dim3(LG_STEP_WAVES * LG_BLOCK), 0, st, a);
+    hipLaunchKernelGGL(k_roll_finish, dim3(1), dim3(64), 0, st, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -75,7 +75,7 @@ struct PolicyArgs {
 // the caller places the barrier).  Layer widths in tiles of 16 (D0T = ceil(num_obs/16)); the output layer is one tile.
 template <int D0T, int D1T, int D2T, int D3T>
 LG_DEV void policy_forward(const PolicyArgs &A, float4 (*xa)[64], float4 (*xb)[64], float4 (*xy)[64], int block, int wave, int lane,
-                           int64_t step, float (*lds_act)[16]) {
+                           int64_t step, float (*lds_act)[16], const float (*lds_obs)[48] = nullptr /* the 16 envs' observations in LDS instead of A.obs */) {
     const int g = lane >> 4;
     int env = block * 16 + (lane & 15);
     const bool live = env < A.num_envs;
@@ -85,7 +85,7 @@ LG_DEV void policy_forward(const PolicyArgs &A, float4 (*xa)[64], float4 (*xb)[6
     for (int t = wave; t < D0T; t += LG_POLICY_WAVES) {
         float v[4];
 #pragma unroll
-        for (int r = 0; r < 4; r++) { int k = 16 * t + 4 * g + r; v[r] = k < A.num_obs ? o[k] : 0.0f; }
+        for (int r = 0; r < 4; r++) { int k = 16 * t + 4 * g + r; v[r] = k < A.num_obs ? (lds_obs ? lds_obs[lane & 15][k] : o[k]) : 0.0f; }
         xa[t][lane] = make_float4(v[0], v[1], v[2], v[3]);
     }
     __syncthreads();

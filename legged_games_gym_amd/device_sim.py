@@ -86,6 +86,25 @@ class DeviceSim:
                              fused_actor.seed, deterministic, counter, self._stream())
         return actions, mean
 
+    def rollout_policy(self, fused_actor, storage: Dict[str, torch.Tensor], counter: int, deterministic: bool = False):
+        """``lg_rollout_policy``: ``steps`` fused policy steps in ONE launch.  ``storage``: contiguous float32 ``obs`` [T+1, N, num_obs]
+        (``obs[0]`` = the current observations), ``actions`` / optional ``mean`` [T, N, num_actions], ``rew`` [T, N], and bool / uint8
+        ``dones`` / ``time_outs`` [T, N], all on the sim device."""
+        T, N, n = storage["actions"].shape[0], self.params.num_envs, self.robot.num_dof
+        want = {"obs": (T + 1, N, self.params.num_obs), "actions": (T, N, n), "rew": (T, N), "dones": (T, N), "time_outs": (T, N)}
+        if "mean" in storage and storage["mean"] is not None:
+            want["mean"] = (T, N, n)
+        for k, shape in want.items():
+            t = storage[k]
+            ok_dtype = t.dtype in (torch.bool, torch.uint8) if k in ("dones", "time_outs") else t.dtype == torch.float32
+            if tuple(t.shape) != shape or not t.is_contiguous() or t.device != self.device or not ok_dtype:
+                raise ValueError(f"rollout storage '{k}' must be a contiguous {shape} tensor on {self.device} (got {tuple(t.shape)}, {t.dtype}, {t.device})")
+        mean = storage.get("mean")
+        self._keep_roll = storage
+        self.sim.rollout_policy(fused_actor.handle, T, storage["obs"].data_ptr(), storage["actions"].data_ptr(), mean.data_ptr() if mean is not None else None,
+                                storage["rew"].data_ptr(), storage["dones"].data_ptr(), storage["time_outs"].data_ptr(), fused_actor.seed, deterministic,
+                                counter, self._stream())
+
     def reset_idx(self, env_ids: torch.Tensor, counter: int):
         ids = env_ids.to(device=self.device, dtype=torch.int32).contiguous()
         if ids.numel() == 0:

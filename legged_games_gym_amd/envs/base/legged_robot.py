@@ -208,6 +208,56 @@ class LeggedRobot(BaseTask):
             return self.obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf, self.extras
         return replay
 
+    def rollout_policy(self, fused_actor, steps, storage=None, deterministic=False):
+        """``steps`` rollout steps (``actions = actor(obs) + std * eps``; ``step(actions)``) as ONE launch (``lg_rollout_policy``): what
+        the caller's ``for i in range(num_steps_per_env)`` loop does, with identical results, but every workgroup walks through the
+        steps of its own envs without meeting the others at each step boundary.  Returns the rollout storage: ``obs`` [T+1, N, num_obs]
+        (``obs[0]`` = the observations before the first step), ``actions`` / ``mean`` [T, N, num_actions], ``rew`` [T, N], bool ``dones`` /
+        ``time_outs`` [T, N].  ``self.obs_buf`` becomes ``obs[T]``; ``rew_buf`` / ``reset_buf`` / ``time_out_buf`` hold the last step's
+        values as after ``step()``.  Raises RuntimeError when the sim / actor pair is not the compiled fused shape."""
+        if self.cfg.commands.curriculum:
+            raise NotImplementedError("commands.curriculum is a host-side rule evaluated between steps: use step()")
+        N, T = self.num_envs, int(steps)
+        if storage is None:
+            dev, f32 = self.device, torch.float32
+            storage = {"obs": torch.empty(T + 1, N, self.num_obs, device=dev, dtype=f32), "actions": torch.empty(T, N, self.num_actions, device=dev, dtype=f32),
+                       "mean": torch.empty(T, N, self.num_actions, device=dev, dtype=f32), "rew": torch.empty(T, N, device=dev, dtype=f32),
+                       "dones": torch.empty(T, N, device=dev, dtype=torch.bool), "time_outs": torch.empty(T, N, device=dev, dtype=torch.bool)}
+        if storage["obs"][0].data_ptr() != self.obs_buf.data_ptr():
+            storage["obs"][0].copy_(self.obs_buf)
+        self._sim.rollout_policy(fused_actor, storage, -1 if self._capturing else self.common_step_counter + 1, deterministic)
+        self.common_step_counter += T
+        self.obs_buf = storage["obs"][T]
+        return storage
+
+    def make_graphed_rollout(self, fused_actor, steps, warmup=1):
+        """``rollout_policy(fused_actor, steps)`` on a fixed storage captured into one HIP graph (copy of the last observations to
+        ``obs[0]``, the accumulator zeroing, the multi-step kernel, the extras finisher): returns ``(replay, storage)``."""
+        if self.cfg.commands.curriculum:
+            raise NotImplementedError("commands.curriculum needs eager steps (host-side rule between steps)")
+        sim = self._sim
+        storage = None
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):               # (the first call allocates the library's workspace: outside capture)
+                storage = self.rollout_policy(fused_actor, steps, storage=storage)
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        sim.buf["step_counter"].fill_(self.common_step_counter)
+        graph = torch.cuda.CUDAGraph()
+        T = int(steps)
+        with torch.cuda.graph(graph):
+            storage["obs"][0].copy_(storage["obs"][T])
+            sim.rollout_policy(fused_actor, storage, -1, False)
+        self._rollout_graph = graph
+        self.obs_buf = storage["obs"][T]
+
+        def replay():
+            graph.replay()
+            self.common_step_counter += T
+            return storage
+        return replay, storage
+
     def reset_idx(self, env_ids):
         """Reset the listed envs (reference :147-191) through ``lg_reset_idx``."""
         if len(env_ids) == 0:
