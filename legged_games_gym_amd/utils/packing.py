@@ -31,6 +31,15 @@ class EngineOptions:
     armature: float = 0.0
 
 
+# Robot-specific engine options (keyed by ``asset.name``), used when the config carries no ``sim.engine`` of its own.
+# A1 (12.5 kg, P-controlled legs with Kp 20 / Kd 0.5): on the 1e6 N/m ground spring of the 30-50 kg robots its feet chatter -- joint-speed rms
+# of the STANDING robot 0.25 rad/s against 0.08 at 1e5 N/m, foot normal force 33 % above the weight under exploration noise -- and PPO with
+# the reference's defaults does not ignite (action std 1 -> 3, reward -> 0) for any stiffness above ~1.2e5 N/m, while it trains for every
+# value from 1e4 to 1e5 (tools/a1_probe.py, DESIGN.md "A1").  Normal / tangential damping do not matter; ANYmal-C / -B are insensitive to the
+# stiffness over 1e5 .. 1e6.  Static foot penetration at 5e4 N/m: 0.6 mm.
+ROBOT_ENGINE_OPTIONS = {"a1": EngineOptions(contact_stiffness=5.0e4)}
+
+
 def reward_layout(cfg, dt: float) -> Tuple[np.ndarray, np.ndarray, List[str]]:
     """scale*dt per term id, slot per term id (-1 absent), slot names.
     Mirrors _prepare_reward_function: zero scales dropped, rest multiplied by dt,
@@ -55,7 +64,7 @@ def reward_layout(cfg, dt: float) -> Tuple[np.ndarray, np.ndarray, List[str]]:
 def build_params(cfg, model, sim_dt: float, num_envs: int, seed: int, gravity=(0.0, 0.0, -9.81),
                  engine: EngineOptions = None, terrain=None, contact_offset: float = 0.01):
     """Returns (lg_params, reward_slot_names)."""
-    engine = engine or getattr(cfg.sim, "engine", None) or EngineOptions()
+    engine = engine or getattr(cfg.sim, "engine", None) or ROBOT_ENGINE_OPTIONS.get(getattr(cfg.asset, "name", None)) or EngineOptions()
     p = capi.lg_params()
     n = model.num_dof
     dt = cfg.control.decimation * sim_dt
