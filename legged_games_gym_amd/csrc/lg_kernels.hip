@@ -60,7 +60,8 @@ struct CassieTraits {          // pelvis + 2 legs x 6 joints; points: toe capsul
     static constexpr int grp_cap_hi(int) { return 1; }
 };
 template <class T> struct Tab { static constexpr int GRP = T::L * LG_JS + 4 * T::NPT;                 // bounding radius of each point group
-                          static constexpr int STRIDE = GRP + T::NGRP + 1; };
+                          static constexpr int BPT = GRP + T::NGRP + 1;                           // base collision point owned by the lane of this limb (x, y, z, radius)
+                          static constexpr int STRIDE = BPT + 4; };
 // per-joint offsets inside the limb table
 enum { J_POS = 0, J_ROT = 3, J_AXIS = 12, J_MASS = 15, J_COM = 16, J_INERTIA = 19, J_LO = 25, J_HI = 26, J_VLIM = 27,
        J_ARM = 28, J_DAMP = 29, J_KP = 30, J_KD = 31, J_Q0 = 32, J_TLIM = 33, J_SLO = 34, J_SHI = 35, J_DVL = 36,
@@ -588,12 +589,9 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, int lane_k, float 
         // joins the lane's limb contribution before the butterfly, their force is butterfly-summed afterwards
         static_assert(K <= LG_MAX_BASE_POINTS, "one base point per lane at most");
         {
-            float bp[4] = {A.base.pts[0][0], A.base.pts[0][1], A.base.pts[0][2], A.base.pts[0][3]};
-            if constexpr (SC) { const float4 w = sc->base_pts[lane_k]; bp[0] = w.x; bp[1] = w.y; bp[2] = w.z; bp[3] = w.w; }     // staged copy (see SelfLds)
-            else {
-#pragma unroll
-                for (int i = 1; i < K; i++) if (lane_k == i) { bp[0] = A.base.pts[i][0]; bp[1] = A.base.pts[i][1]; bp[2] = A.base.pts[i][2]; bp[3] = A.base.pts[i][3]; }
-            }
+            // from the lane's limb table (LDS): selecting A.base.pts[lane_k] out of the by-value kernel arguments is a lane-dependent index
+            // that hipcc, depending on unrelated code, turns into a scratch copy of the array with VGPR-indexed loads (rough 64.9 -> 68.3 us)
+            const float bp[4] = {tab[Tab<T>::BPT], tab[Tab<T>::BPT + 1], tab[Tab<T>::BPT + 2], tab[Tab<T>::BPT + 3]};
             cb.r = mul(R0, v3(bp[0], bp[1], bp[2]));
             cb.vc = v0 + cross(w0, cb.r);
             cb.depth = bp[3];                                            // radius until the ground height arrives
@@ -680,6 +678,7 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, int lane_k, float 
         for (int j = 0; j < L; j++) bt_load(bt[j], threadIdx.x % LG_BLOCK, I0[j], p0[j]);
     }
     bool any_self = false;                                 // wave-uniform
+    bool sc_missed = false;                                // the self-collision hand-over poll ran out (sticky device status)
     LG_PROF(PF_TORQUE);
     // ---- articulated-body passes with the contact impedances folded in
     S6 U[L], acc0;
@@ -699,7 +698,7 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, int lane_k, float 
                     if (min(r1, min(r2, r3)) >= substep_no) { arrived = true; break; }
                     __builtin_amdgcn_s_sleep(1);
                 }
-                if (!arrived && ln == 0) lg_report(A.status, LG_STATUS_SELF_COLLISION_TIMEOUT);
+                sc_missed |= !arrived;                     // reported after the passes
                 __builtin_amdgcn_wave_barrier();
             } else {
                 __builtin_amdgcn_wave_barrier();           // this wave's own LDS writes (kinematics loop) precede the reads: one wave, in order
@@ -790,6 +789,7 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, int lane_k, float 
         LG_PROF(PF_OUTWARD);
     }
 
+    if constexpr (SC) if (sc_missed && threadIdx.x % LG_BLOCK == 0) lg_report(A.status, LG_STATUS_SELF_COLLISION_TIMEOUT);
     // ---- semi-implicit Euler
 #pragma unroll
     for (int j = 0; j < L; j++) {
@@ -1275,6 +1275,7 @@ template <class T, bool NET, bool HF, int NW, bool SC = false> struct HelperWave
         const lg_buffers &B = A.B;
         const lg_params &P = A.P;
         const int j = wave - 1;
+        bool missed = false;                                     // a hand-over poll of this wave ran out (sticky device status, lg_report)
         LstmSplit st;
         float (*part[4])[4] = {st.h0, st.c0, st.h1, st.c1};
         float *row[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -1304,8 +1305,9 @@ template <class T, bool NET, bool HF, int NW, bool SC = false> struct HelperWave
                     volatile int *flag = &sh.fk_ready;
                     // bounded: ~0.3 s at most, then go on with whatever is in LDS (wrong numbers beat a hung CU; the rigid-body
                     // wave publishes the flag unconditionally every sub-step, so the bound is never reached in a correct run)
-                    for (int spin = 0; *flag < sub0 + it + 1 && spin < A.spin_limit; spin++) __builtin_amdgcn_s_sleep(1);
-                    if (*flag < sub0 + it + 1 && lane == 0) lg_report(A.status, LG_STATUS_FRAME_HANDOVER_TIMEOUT);
+                    int spin = 0;
+                    for (; *flag < sub0 + it + 1 && spin < A.spin_limit; spin++) __builtin_amdgcn_s_sleep(1);
+                    missed |= spin >= A.spin_limit;                // reported once, at the end of the step (nothing but a compare inside the loop)
 #pragma unroll 1
                     for (int b = j; b < T::L; b += NW - 1) {
                         const float4 f0 = sh.fk[b][0][lane], f1 = sh.fk[b][1][lane], f2 = sh.fk[b][2][lane], f3 = sh.fk[b][3][lane];
@@ -1407,6 +1409,7 @@ template <class T, bool NET, bool HF, int NW, bool SC = false> struct HelperWave
             }
         }
         if (P.measure_heights) hc.write_obs(A, e, k + T::K * wave, live, step, sh.root_z[lane], un);
+        if (missed && lane == 0) lg_report(A.status, LG_STATUS_FRAME_HANDOVER_TIMEOUT);
         if (NET) {                                                 // reset envs: actuator state zeroed (anymal.py:59-60), over the early write-back above
             const bool reset = sh.rst[lane] != 0 && live;
             if (__ballot(reset) != 0 && reset) {
@@ -2131,6 +2134,8 @@ template <class T> static void fill_limb_table(const lg_params &P, const lg_robo
                 }
             tk[Tab<T>::GRP + g] = R * 1.0001f;
         }
+        for (int c = 0; c < 4; c++) tk[Tab<T>::BPT + c] = 0.0f;                  // lane k of an env owns base point k
+        if (k < M.num_base_points) { memcpy(tk + Tab<T>::BPT, M.base_points[k].pos, 12); tk[Tab<T>::BPT + 3] = M.base_points[k].radius; }
     }
 }
 

@@ -14,9 +14,4 @@ task_registry.register("anymal_c_rough", Anymal, AnymalCRoughCfg(), AnymalCRough
 task_registry.register("anymal_c_flat", Anymal, AnymalCFlatCfg(), AnymalCFlatCfgPPO())
 task_registry.register("anymal_b", Anymal, AnymalBRoughCfg(), AnymalBRoughCfgPPO())
 task_registry.register("a1", LeggedRobot, A1RoughCfg(), A1RoughCfgPPO())
-task_registry.experimental["a1"] = (
-    "with the reference's PPO defaults (entropy_coef 0.01, only_positive_rewards) training does not converge on the built-in "
-    "engine -- under N(0,1) actions this A1 model almost never falls (1 reset per ~5000 env-steps, ANYmal: 1 per ~500), the "
-    "entropy bonus outweighs the reward signal and the action std drifts upwards (DESIGN.md, 'A1 caveat').  The step itself is "
-    "parity-green against the CPU oracle; fidelity against PhysX is unpinned.  entropy_coef = 0 learns to balance.")
 task_registry.register("cassie", Cassie, CassieRoughCfg(), CassieRoughCfgPPO())

@@ -122,14 +122,22 @@ def test_runner_scalar_log_uses_rsl_rl_tag_names(tmp_path):
     assert lines[2].split(",")[cols.index("Episode/rew_torques")] == "-0.25"
 
 
-def test_a1_is_flagged_experimental_and_custom_actuator_files_are_refused(tmp_path):
-    """`make_env('a1')` must not hand out a task known not to train without saying so; a user's own TorchScript
-    actuator file must not be silently replaced by the bundled net."""
+def test_no_task_is_flagged_experimental_and_custom_actuator_files_are_refused(tmp_path):
+    """`make_env` warns for tasks registered in `task_registry.experimental` (a1 was, until round 3: it trains with the reference's
+    PPO defaults since its ground stiffness is set per robot, packing.ROBOT_ENGINE_OPTIONS); a user's own TorchScript actuator file
+    must not be silently replaced by the bundled net."""
     import numpy as np
     import pytest
     from legged_games_gym_amd.envs import task_registry
+    from legged_games_gym_amd.envs.configs import A1RoughCfg, AnymalCFlatCfg
     from legged_games_gym_amd.utils import packing
-    assert "a1" in task_registry.experimental and "anymal_c_flat" not in task_registry.experimental
+    from legged_games_gym_amd.utils.model_compiler import load_model
+    assert not task_registry.experimental
+    a1, anymal = A1RoughCfg(), AnymalCFlatCfg()
+    pa, _ = packing.build_params(a1, load_model(a1.asset.file), a1.sim.dt, 4, 1)
+    pb, _ = packing.build_params(anymal, load_model(anymal.asset.file), anymal.sim.dt, 4, 1)
+    assert abs(pa.contact_stiffness - 5.0e4) < 1e-3 and abs(pb.contact_stiffness - 1.0e6) < 1e-3
+    assert pa.contact_damping == pb.contact_damping and pa.friction_damping == pb.friction_damping
     assert packing.load_actuator_weights("/somewhere/resources/actuator_nets/anydrive_v3_lstm.pt").size == 972
     assert packing.load_actuator_weights(None).size == 972
     with pytest.raises(ValueError, match="compile_models"):
