@@ -37,7 +37,7 @@ sys.path.insert(0, REPO)
 BYTES_PER_ENV_STEP = {"anymal_c_flat": 4022, "anymal_c_rough": 4762, "cassie": 1442, "a1": 1690, "anymal_b": 4762}
 HBM_PEAK_GBS = 8000.0                                                                 # MI355X_MICROARCH.md
 FP32_VECTOR_PEAK_TFLOPS = 157.3                                                       # MI355X_MICROARCH.md (non-matrix fp32)
-PMC_SUMMARY = os.path.join(REPO, "profiles", "r02_pmc_summary.json")
+PMC_SUMMARY = os.path.join(REPO, "profiles", "r03_pmc_summary.json")     # tools/collect_r03.sh + tools/pmc_summary_r03.py: per task, the bench's own launch mode
 
 
 def parse_args():
@@ -54,6 +54,7 @@ def parse_args():
     ap.add_argument("--torch-policy", action="store_true", help="same as --policy torch")
     ap.add_argument("--graph-steps", type=int, default=20, help="policy steps captured per HIP-graph replay (clamped to a divisor of --steps and --warmup)")
     ap.add_argument("--no-fused-step", action="store_true", help="keep actor kernel and step kernel separate (lg_policy_act + lg_step)")
+    ap.add_argument("--f32-actor", action="store_true", help="wide actors (235/169-512-256-128): the f32-MFMA kernel instead of the split-bf16 one (lg_mlp_wide_set_precision(0))")
     ap.add_argument("--no-rollout", action="store_true", help="one launch per policy step (lg_step_policy) instead of one per --graph-steps steps (lg_rollout_policy): the A/B of the multi-step kernel")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one captured HIP graph per step")
     ap.add_argument("--training-iters", type=int, default=-1, help="PPO iterations timed for the ppo_training object (0 = skip; -1 = 100 for anymal_c_flat, 20 otherwise)")
@@ -174,6 +175,9 @@ def worker(a):
     from legged_games_gym_amd.rl import ActorCritic
     from legged_games_gym_amd.utils.helpers import class_to_dict
 
+    if a.f32_actor:
+        from legged_games_gym_amd import capi as _capi
+        _capi.load_library().lg_mlp_wide_set_precision(0)
     args = get_args(["--task", a.task, "--num_envs", str(a.num_envs), "--headless", "--sim_device", f"cuda:{local_rank}",
                      "--rl_device", f"cuda:{local_rank}"])
     env_cfg, train_cfg = task_registry.get_cfgs(a.task)
@@ -205,23 +209,27 @@ def worker(a):
 
     fused_step = False                                    # actor fused INTO the step kernel (lg_step_policy): flat actor only
     rollout_kernel = False                                # ... and G steps per launch (lg_rollout_policy)
-    G = 1
-    if not a.no_graph:
-        G = max(g for g in range(1, max(1, a.graph_steps) + 1) if a.steps % g == 0 and a.warmup % g == 0)
+    G = max(g for g in range(1, max(1, a.graph_steps) + 1) if a.steps % g == 0 and a.warmup % g == 0)      # policy steps per graph replay / per rollout launch
     with torch.inference_mode():
         if not use_torch and not a.no_fused_step:
             try:
-                if not a.no_graph and not a.no_rollout and G > 1:
+                if not a.no_rollout and G > 1:
                     try:                                       # G policy steps per LAUNCH (lg_rollout_policy), one HIP graph per segment
-                        one_step, _roll_storage = env.make_graphed_rollout(fused, G)
+                        if a.no_graph:                         # (eager: every dispatch gets its own counter row under rocprofv3 --pmc)
+                            _roll_storage = env.rollout_policy(fused, G)
+                            one_step = lambda: env.rollout_policy(fused, G, storage=_roll_storage)
+                        else:
+                            one_step, _roll_storage = env.make_graphed_rollout(fused, G)
                         rollout_kernel = True
                     except RuntimeError as exc:
                         if "multi-step rollout kernel" not in str(exc):
                             raise
                 if not rollout_kernel:
+                    if a.no_graph:
+                        G = 1
                     one_step = env.make_graphed_policy_step(fused, steps_per_replay=G) if not a.no_graph else (lambda: env.step_policy(fused))
-                if a.no_graph:
-                    one_step()
+                    if a.no_graph:
+                        one_step()
                 fused_step = True
             except RuntimeError as exc:
                 if "fused policy step" not in str(exc):    # only "no fused kernel for this sim / actor pair" is a fall-back case
@@ -230,6 +238,8 @@ def worker(a):
         if fused_step:
             pass
         elif a.no_graph:
+            G = 1
+
             def one_step():
                 env.step(policy_act(env.obs_buf))             # the full VecEnv step (one lg_step call)
         else:
@@ -267,7 +277,7 @@ def worker(a):
         if fused_step and not a.no_graph:
             kern_ms_each = [1e3 * e / a.steps for e in evs]     # the timed graph IS G x k_step<..., POL>: same replays, same region
             kern_method = (f"HIP events on the launch stream around the {a.steps // G} graph replays of the timed region itself "
-                           f"(median of {repeats} regions; includes the ~1 us gaps between launches" + (f" and, per {G}-step launch, the observation copy, the accumulator zeroing and the extras finisher" if rollout_kernel else "") + ")")
+                           f"(median of {repeats} regions; includes the ~1 us gaps between launches" + (f" and, per {G}-step launch, the extras finisher" if rollout_kernel else "") + ")")
         else:
             KG = 20
             fixed_actions = (policy_act(env.obs_buf) if not fused_step else fused.act(env.obs_buf)).clone()
@@ -325,11 +335,13 @@ def worker(a):
         bpe = BYTES_PER_ENV_STEP.get(a.task, 4022)
         traffic, mfma_busy, pm_src = None, None, None   # PMC figures per k_step launch from the committed rocprofv3 passes (same workload only)
         try:
-            pm = json.load(open(PMC_SUMMARY))
-            if a.task == "anymal_c_flat" and a.num_envs == 4096:
-                traffic = pm["k_step_traffic_bytes"]["fetch_doubled_sum"]
-                mfma_busy = 100.0 * pm["k_step_issue"]["mfma_busy_frac_of_busy_cycles"]
-                pm_src = os.path.relpath(PMC_SUMMARY, REPO) + " (rocprofv3 --pmc passes: FETCH_SIZE / WRITE_SIZE KiB, 2*FETCH+WRITE; SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES)"
+            pm = json.load(open(PMC_SUMMARY))["tasks"].get(a.task)
+            if pm and pm["envs_per_gpu"] == a.num_envs:       # counters of the same workload only; per launch of the dominant kernel, like `achieved`
+                per_step = pm["k_step"]["steps_per_launch"]
+                traffic = pm["k_step"]["traffic_bytes_per_launch"] / per_step * (G if rollout_kernel else 1)
+                mfma_busy = 100.0 * pm["k_step"]["mfma_busy_frac_of_busy_cycles"]
+                pm_src = (os.path.relpath(PMC_SUMMARY, REPO) + f" (rocprofv3 --pmc passes of `{pm['command']}`: FETCH_SIZE / WRITE_SIZE KiB per dispatch of {pm['k_step']['kernel']}, "
+                          f"2*FETCH+WRITE, {per_step} policy step(s) per dispatch; SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES)")
         except Exception:
             pass
         achieved = bpe * a.num_envs / (kern_ms * 1e-3) / 1e9
@@ -338,16 +350,18 @@ def worker(a):
         tflops = step_flops * a.num_envs / (kern_ms * 1e-3) / 1e12
         kname = {"anymal_c_flat": "k_step<AnymalTraits,NET,plane" + ((",POL,ROLL> (actor + step, %d steps per launch)" % G) if rollout_kernel else ",POL> (actor + step)" if fused_step else ">"),
                  "cassie": "k_step<CassieTraits,PD,HF>"}.get(a.task, "k_step<AnymalTraits," + ("NET" if getattr(env.cfg.control, "use_actuator_network", False) else "PD") + ",HF>")
+        wide_bf16 = (not use_torch) and (not fused_step) and capi_wide_precision() == 1
+        dtype_text = "f32" if not wide_bf16 else "f32 physics + bf16x3 actor (split-bf16 products hi*hi + hi*lo + lo*hi with f32 accumulation: 16 significand bits per operand; --f32-actor times the f32-MFMA actor)"
         out = {
             "metric": "env-steps/sec (whole node), ANYmal-C flat 4096 envs/GPU" if a.task == "anymal_c_flat" else f"env-steps/sec (whole node), {a.task}",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": dtype_text, "data": "synthetic",
             "config": {"workload": workload_text(a.task, env, pol, a.num_envs),
                        "envs_per_gpu": a.num_envs, "decimation": int(env.cfg.control.decimation), "sim_dt": float(env.sim_params.dt),
                        "parallelism": f"env-sharded x{world}", "state_finite": finite,
                        "launch": (f"lg_rollout_policy: ONE launch of k_step<...,POL,ROLL> per {G} policy steps (actor fused into the step, every workgroup walks through the {G} steps of its own 16 envs; "
-                                  f"per-step obs / actions / rewards / dones to rollout storage), replayed as a HIP graph with its observation copy, accumulator zeroing and extras finisher") if rollout_kernel else
+                                  f"per-step obs / actions / rewards / dones to rollout storage), " + ("eager launches" if a.no_graph else "replayed as a HIP graph") + " with its extras finisher") if rollout_kernel else
                                  (("eager" if a.no_graph else f"HIP graph of {G} policy steps per replay") + (": ONE kernel per step, actor fused into the step (lg_step_policy)" if fused_step else " (policy + lg_step)")
                                   + ("" if a.no_graph or os.environ.get("LG_DEFER_EXTRAS", "1") == "0" else "; extras[\"episode\"] deferred to the next launch, one lg_extras_flush node per replay")),
                        "policy": "torch ops (hipBLASLt)" if use_torch else ("MFMA actor inside k_step (v_mfma_f32_16x16x4_f32, 4 waves)" if fused_step else "actor kernel lg_policy_act: k_policy_act_wide, 32 envs per workgroup, split-bf16 products (hi*hi + hi*lo + lo*hi, f32 accumulate) on v_mfma_f32_32x32x16_bf16")},
@@ -355,6 +369,8 @@ def worker(a):
             "timing": f"median of {repeats} timed regions of exactly {a.steps} steps each (a region shorter than {a.min_timed_ms:g} ms is repeated)" if repeats > 1 else f"one timed region of {a.steps} steps",
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": pm_src, "kernel": kname,
+                         "policy_steps_per_launch": G if rollout_kernel else 1,
+                         "algorithmic_bytes_per_launch": bpe * a.num_envs * (G if rollout_kernel else 1), "launch_ms": kern_ms * (G if rollout_kernel else 1),
                          "kernel_ms": kern_ms, "kernel_ms_method": kern_method,
                          "algorithmic_bytes_per_env_step": bpe,
                          "flops": {"per_env_step": step_flops, "breakdown": fl, "achieved_tflops": tflops, "peak_tflops": FP32_VECTOR_PEAK_TFLOPS,
@@ -380,7 +396,7 @@ def worker(a):
         if training is not None:
             out["ppo_training"] = training
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a)
+            out["cpu_baseline"] = cpu_baseline(a, env)
         sys.__stdout__.write(json.dumps(out) + "\n")         # (the watchdog may fire while the leg has sys.stdout redirected)
         sys.__stdout__.flush()
 
@@ -471,6 +487,14 @@ def training_leg(a, iters, rank, local_rank, world, coll_dev, ranks_seen, backen
     return out
 
 
+def capi_wide_precision():
+    """Current lg_mlp_wide_set_precision mode (0 = f32 MFMA, 1 = split-bf16) without changing it."""
+    from legged_games_gym_amd import capi
+    lib = capi.load_library()
+    mode = lib.lg_mlp_wide_set_precision(-1)          # an invalid mode only returns the current one
+    return int(mode)
+
+
 def _usable_cores():
     """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -483,19 +507,29 @@ def _usable_cores():
     return max(1, min(n, int(os.environ.get("LG_BENCH_MAX_THREADS", "64"))))
 
 
-def cpu_baseline(a):
-    """Time the CPU oracle on the same workload shape (own restatement: PhysX CPU is unavailable)."""
+def cpu_baseline(a, env):
+    """Time the CPU oracle on the same workload (own restatement: PhysX CPU is unavailable): the GPU leg's terrain (the same int16 height
+    field, the same contact rule: bilinear patches, or vertical faces with --trimesh), env origins / terrain levels, friction and mass."""
     import numpy as np
-    from tests.common import make_setup, grid_origins, randomize_env_params
+    from tests.common import make_setup, grid_origins
     from oracle.oracle import OracleSim
     cores = _usable_cores()
     N = a.num_envs
-    cfg, robot, p, names, model, w = make_setup(a.task, N)
+    terr = getattr(env, "terrain", None) if env.cfg.terrain.mesh_type in ("heightfield", "trimesh") else None
+    mesh = "trimesh" if a.trimesh else "heightfield"
+
+    def tweak(cfg):
+        if terr is not None:
+            cfg.terrain.mesh_type = mesh if cfg.terrain.mesh_type == "trimesh" else cfg.terrain.mesh_type
+    cfg, robot, p, names, model, w = make_setup(a.task, N, plane=(terr is None), terrain=terr, tweak=tweak)
     o = OracleSim(p, model, robot, w, threads=cores)
-    o.buf["env_origins"][:] = grid_origins(N)
-    fr, dm = randomize_env_params(N, 1)
-    o.buf["friction_coeffs"][:] = fr
-    o.buf["base_mass_delta"][:] = dm
+    if terr is not None:
+        o.set_terrain(terr.heightsamples, terr.env_origins)
+        for k in ("terrain_levels", "terrain_types"):
+            o.buf[k][:] = env._sim.buf[k].cpu().numpy()
+    o.buf["env_origins"][:] = env._sim.buf["env_origins"].cpu().numpy()
+    o.buf["friction_coeffs"][:] = env._sim.buf["friction_coeffs"].cpu().numpy()
+    o.buf["base_mass_delta"][:] = env._sim.buf["base_mass_delta"].cpu().numpy()
     o.reset_idx(np.arange(N, dtype=np.int32), 0)
     rng = np.random.default_rng(0)
     acts = rng.standard_normal((8, N, 12)).astype(np.float32)
@@ -508,8 +542,9 @@ def cpu_baseline(a):
         o.step(acts[i % 8], 3 + i)
     dt = time.perf_counter() - t0
     return {"value": N * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{N} envs x {steps} policy steps of the same workload on the plane (env step only, N(0,1) actions), "
-                      f"oracle/lg_oracle.c with OpenMP over envs; PhysX CPU path of the reference is not runnable here"}
+            "sample": f"{N} envs x {steps} policy steps of the same workload (env step only, N(0,1) actions) on "
+                      + ("the plane" if terr is None else f"the GPU leg's {terr.tot_rows}x{terr.tot_cols} int16 curriculum height field ({'vertical-face' if p.hf_step_threshold > 0 else 'bilinear height-field'} contact, same env origins / terrain levels)")
+                      + ", the GPU leg's friction / base-mass randomisation; oracle/lg_oracle.c with OpenMP over envs; PhysX CPU path of the reference is not runnable here"}
 
 
 if __name__ == "__main__":

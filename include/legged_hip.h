@@ -247,6 +247,8 @@ int  lg_step_policy(lg_sim *sim, lg_policy *p, const float *obs, float *actions,
 typedef struct {
     int32_t  steps;
     float   *obs;
+    const float *obs0;     /* optional: the input of the first step lives HERE (typically obs[steps] of the previous segment in the same storage);
+                              every workgroup copies its envs' rows to obs[0] while it reads them, so no copy kernel is needed between segments */
     float   *actions;
     float   *mean;
     float   *rew;

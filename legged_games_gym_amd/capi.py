@@ -89,7 +89,7 @@ _PF, _PU8, _PI64, _PI32, _PI16 = C.POINTER(f32), C.POINTER(u8), C.POINTER(i64), 
 
 class lg_rollout_buffers(C.Structure):
     """Rollout storage of ``lg_rollout_policy`` (include/legged_hip.h): [steps(+1)][N][...] device arrays owned by the caller."""
-    _fields_ = [("steps", i32), ("obs", _PF), ("actions", _PF), ("mean", _PF), ("rew", _PF), ("dones", _PU8), ("time_outs", _PU8)]
+    _fields_ = [("steps", i32), ("obs", _PF), ("obs0", _PF), ("actions", _PF), ("mean", _PF), ("rew", _PF), ("dones", _PU8), ("time_outs", _PU8)]
 
 
 LG_MAX_ROLL_STEPS = 256
@@ -363,10 +363,10 @@ class Sim:
                                             int(common_step_counter), stream))
 
     def rollout_policy(self, policy_handle, steps: int, obs_ptr: int, actions_ptr: int, mean_ptr, rew_ptr: int, dones_ptr: int, time_outs_ptr: int,
-                       seed: int, deterministic: bool, common_step_counter: int, stream: int = 0):
+                       seed: int, deterministic: bool, common_step_counter: int, stream: int = 0, obs0_ptr=None):
         r = lg_rollout_buffers()
         r.steps = int(steps)
-        for name, ptr in (("obs", obs_ptr), ("actions", actions_ptr), ("mean", mean_ptr), ("rew", rew_ptr), ("dones", dones_ptr), ("time_outs", time_outs_ptr)):
+        for name, ptr in (("obs", obs_ptr), ("obs0", obs0_ptr), ("actions", actions_ptr), ("mean", mean_ptr), ("rew", rew_ptr), ("dones", dones_ptr), ("time_outs", time_outs_ptr)):
             setattr(r, name, C.cast(C.c_void_p(ptr or 0), dict(lg_rollout_buffers._fields_)[name]))
         self._check(self.lib.lg_rollout_policy(self.handle, policy_handle, C.byref(r), int(seed), int(bool(deterministic)), int(common_step_counter), stream))
 

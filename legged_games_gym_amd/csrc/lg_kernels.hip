@@ -74,6 +74,7 @@ struct BaseTab { float mass, com[3], inertia[6]; float pts[LG_MAX_BASE_POINTS][4
 struct RollArgs {
     int      steps;
     float   *obs;              // [steps + 1][N][num_obs]: obs[0] is the input of step 0, step t writes obs[t + 1]
+    const float *obs0;         // if set: the input of step 0 lives here (e.g. obs[steps] of the previous segment); every workgroup copies its rows to obs[0]
     float   *actions, *mean;   // [steps][N][num_actions] (mean may be null)
     float   *rew;              // [steps][N]
     uint8_t *done, *time_outs; // [steps][N]
@@ -1497,6 +1498,12 @@ __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
         if (ROLL) {
             PolicyArgs pa = A.pol;
             pa.obs = A.roll.obs + (size_t)rt * N * P.num_obs;
+            if (rt == 0 && A.roll.obs0) {                      // (kernel-uniform) first step of a segment that continues the previous one: no copy kernel in front
+                pa.obs = A.roll.obs0;
+                const size_t row0 = (size_t)blockIdx.x * 16 * P.num_obs;
+                const int n = min(16, N - (int)blockIdx.x * 16) * P.num_obs;
+                for (int i = tix; i < n; i += NW * LG_BLOCK) A.roll.obs[row0 + i] = A.roll.obs0[row0 + i];
+            }
             pa.actions = A.roll.actions + (size_t)rt * N * ND;
             pa.mean = A.roll.mean ? A.roll.mean + (size_t)rt * N * ND : nullptr;
             policy_forward<3, 8, 4, 2>(pa, pol_xa, pol_xb, pol_xy, blockIdx.x, wave, lane, step, lds_act, rt > 0 ? lds_obs : nullptr);
@@ -1895,10 +1902,6 @@ __global__ void __launch_bounds__(64) k_extras(const KArgs A) {        // behind
 }
 
 // ------------------------------------------------------------------ lg_rollout_policy: around the multi-step launch
-__global__ void __launch_bounds__(256) k_roll_zero(float *extras, int n) {      // (a kernel, not a memset node: small memset nodes inside replayed HIP graphs proved unreliable)
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) extras[i] = 0.0f;
-}
 __global__ void __launch_bounds__(64) k_roll_finish(const KArgs A) {
     // extras["episode"] (legged_robot.py:179-188): the sums of the LAST step of the launch in which any env was reset (the dictionary
     // stays stale otherwise, quirk Q4); the device step counter moves to the last executed step.
@@ -1910,6 +1913,8 @@ __global__ void __launch_bounds__(64) k_roll_finish(const KArgs A) {
     if (last >= 0 && t < R) A.B.episode_means[t] = A.roll.extras[(size_t)last * stride + t] / A.roll.extras[(size_t)last * stride + R] / P.max_episode_length_s;
     __builtin_amdgcn_s_waitcnt(0);
     if (t == 0 && A.B.step_counter) A.B.step_counter[0] = step0 + A.roll.steps - 1;
+    __syncthreads();
+    for (int i = t; i < A.roll.steps * stride; i += 64) A.roll.extras[i] = 0.0f;        // ready for the next segment (zeroed once at allocation)
 }
 
 // ------------------------------------------------------------------ sub-path kernels (parity tests drive these)
@@ -3140,13 +3145,13 @@ int lg_rollout_policy(lg_sim *s, lg_policy *p, const lg_rollout_buffers *r, uint
         if (cap != hipStreamCaptureStatusNone) return fail(-9, "first lg_rollout_policy call on a handle allocates its workspace: make one call outside stream capture");
         HIP_TRY(hipSetDevice(s->device));
         if (hipMalloc(&s->d_roll_extras, sizeof(float) * LG_MAX_ROLL_STEPS * stride) != hipSuccess) return fail(-10, "hipMalloc failed");
+        HIP_TRY(hipMemset(s->d_roll_extras, 0, sizeof(float) * LG_MAX_ROLL_STEPS * stride));      // k_roll_finish leaves it zeroed after every segment
     }
     KArgs a; fill_args(s, a, common_step_counter); a.actions_in = nullptr; a.defer = 0;
     fill_policy_args(p, a.pol, r->obs, r->actions, r->mean, s->P.num_envs, seed, common_step_counter, s->B.step_counter, deterministic);
     a.roll.steps = r->steps; a.roll.obs = r->obs; a.roll.actions = r->actions; a.roll.mean = r->mean; a.roll.rew = r->rew;
     a.roll.done = r->dones; a.roll.time_outs = r->time_outs; a.roll.extras = s->d_roll_extras;
-    const int n = r->steps * stride;
-    hipLaunchKernelGGL(k_roll_zero, dim3((n + 255) / 256), dim3(256), 0, st, s->d_roll_extras, n);
+    a.roll.obs0 = r->obs0;
     if (s->P.self_collision)
         hipLaunchKernelGGL((k_step<AnymalTraits, true, false, true, 4, true, true>), dim3(grid_for<AnymalTraits>(s->P.num_envs)), dim3(LG_STEP_WAVES * LG_BLOCK), 0, st, a);
     else

@@ -86,7 +86,7 @@ class DeviceSim:
                              fused_actor.seed, deterministic, counter, self._stream())
         return actions, mean
 
-    def rollout_policy(self, fused_actor, storage: Dict[str, torch.Tensor], counter: int, deterministic: bool = False):
+    def rollout_policy(self, fused_actor, storage: Dict[str, torch.Tensor], counter: int, deterministic: bool = False, obs0: Optional[torch.Tensor] = None):
         """``lg_rollout_policy``: ``steps`` fused policy steps in ONE launch.  ``storage``: contiguous float32 ``obs`` [T+1, N, num_obs]
         (``obs[0]`` = the current observations), ``actions`` / optional ``mean`` [T, N, num_actions], ``rew`` [T, N], and bool / uint8
         ``dones`` / ``time_outs`` [T, N], all on the sim device."""
@@ -100,10 +100,12 @@ class DeviceSim:
             if tuple(t.shape) != shape or not t.is_contiguous() or t.device != self.device or not ok_dtype:
                 raise ValueError(f"rollout storage '{k}' must be a contiguous {shape} tensor on {self.device} (got {tuple(t.shape)}, {t.dtype}, {t.device})")
         mean = storage.get("mean")
-        self._keep_roll = storage
+        if obs0 is not None and (tuple(obs0.shape) != (N, self.params.num_obs) or not obs0.is_contiguous() or obs0.dtype != torch.float32 or obs0.device != self.device):
+            raise ValueError("obs0 must be a contiguous float32 [num_envs, num_obs] tensor on the sim device")
+        self._keep_roll = (storage, obs0)
         self.sim.rollout_policy(fused_actor.handle, T, storage["obs"].data_ptr(), storage["actions"].data_ptr(), mean.data_ptr() if mean is not None else None,
                                 storage["rew"].data_ptr(), storage["dones"].data_ptr(), storage["time_outs"].data_ptr(), fused_actor.seed, deterministic,
-                                counter, self._stream())
+                                counter, self._stream(), obs0.data_ptr() if obs0 is not None else None)
 
     def reset_idx(self, env_ids: torch.Tensor, counter: int):
         ids = env_ids.to(device=self.device, dtype=torch.int32).contiguous()

@@ -223,16 +223,18 @@ class LeggedRobot(BaseTask):
             storage = {"obs": torch.empty(T + 1, N, self.num_obs, device=dev, dtype=f32), "actions": torch.empty(T, N, self.num_actions, device=dev, dtype=f32),
                        "mean": torch.empty(T, N, self.num_actions, device=dev, dtype=f32), "rew": torch.empty(T, N, device=dev, dtype=f32),
                        "dones": torch.empty(T, N, device=dev, dtype=torch.bool), "time_outs": torch.empty(T, N, device=dev, dtype=torch.bool)}
-        if storage["obs"][0].data_ptr() != self.obs_buf.data_ptr():
-            storage["obs"][0].copy_(self.obs_buf)
-        self._sim.rollout_policy(fused_actor, storage, -1 if self._capturing else self.common_step_counter + 1, deterministic)
+        # the first step starts from the current observations: the kernel reads them where they are (and copies them to obs[0])
+        obs0 = self.obs_buf if storage["obs"][0].data_ptr() != self.obs_buf.data_ptr() else None
+        if obs0 is not None and not (obs0.is_contiguous() and obs0.dtype == torch.float32):
+            storage["obs"][0].copy_(obs0); obs0 = None
+        self._sim.rollout_policy(fused_actor, storage, -1 if self._capturing else self.common_step_counter + 1, deterministic, obs0=obs0)
         self.common_step_counter += T
         self.obs_buf = storage["obs"][T]
         return storage
 
     def make_graphed_rollout(self, fused_actor, steps, warmup=1):
-        """``rollout_policy(fused_actor, steps)`` on a fixed storage captured into one HIP graph (copy of the last observations to
-        ``obs[0]``, the accumulator zeroing, the multi-step kernel, the extras finisher): returns ``(replay, storage)``."""
+        """``rollout_policy(fused_actor, steps)`` on a fixed storage captured into one HIP graph (the multi-step kernel, which starts from
+        the previous replay's ``obs[steps]`` and copies it to ``obs[0]``, and the extras finisher): returns ``(replay, storage)``."""
         if self.cfg.commands.curriculum:
             raise NotImplementedError("commands.curriculum needs eager steps (host-side rule between steps)")
         sim = self._sim
@@ -247,8 +249,7 @@ class LeggedRobot(BaseTask):
         graph = torch.cuda.CUDAGraph()
         T = int(steps)
         with torch.cuda.graph(graph):
-            storage["obs"][0].copy_(storage["obs"][T])
-            sim.rollout_policy(fused_actor, storage, -1, False)
+            sim.rollout_policy(fused_actor, storage, -1, False, obs0=storage["obs"][T])     # continues from the previous replay's last observations
         self._rollout_graph = graph
         self.obs_buf = storage["obs"][T]
 

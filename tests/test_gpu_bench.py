@@ -84,3 +84,24 @@ def test_bench_under_the_drivers_launcher():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["gloo_ranks"] == 2 and out["scaling"] == "weak" and out["value"] > 0
     assert out["ppo_training"]["collectives_per_iteration"]["ranks"] == 2 and "eager launches" in out["ppo_training"]["update_path"]
+
+
+@pytest.mark.parametrize("task", ["anymal_c_rough", "cassie"])
+def test_config_3_and_5_lines_state_what_was_timed(task):
+    """`dtype` names the arithmetic of the kernels actually timed (split-bf16 actor unless --f32-actor), the CPU baseline
+    runs on the GPU leg's own height field, and roofline.traffic comes from a rocprofv3 --pmc pass of that config (profiles/r03_pmc_summary.json)."""
+    out = _run(["--task", task, "--steps", "40", "--warmup", "20", "--training-iters", "0", "--cpu-seconds", "1"])
+    assert "bf16x3 actor" in out["dtype"] and out["dtype"].startswith("f32 physics")
+    assert out["roofline"]["traffic"] is not None and out["roofline"]["traffic"] > 1e6 and "r03_pmc_summary.json" in out["roofline"]["traffic_source"]
+    assert "int16 curriculum height field" in out["cpu_baseline"]["sample"] and "on the plane" not in out["cpu_baseline"]["sample"]
+    assert out["cpu_baseline"]["value"] > 1e4
+    f32 = _run(["--task", task, "--steps", "40", "--warmup", "20", "--training-iters", "0", "--no-cpu-baseline", "--f32-actor"])
+    assert f32["dtype"] == "f32"
+
+
+def test_headline_line_uses_the_rollout_kernel_and_its_own_counters():
+    out = _run(["--steps", "40", "--warmup", "20", "--training-iters", "0", "--no-cpu-baseline"])
+    r = out["roofline"]
+    assert "lg_rollout_policy" in out["config"]["launch"] and r["policy_steps_per_launch"] == 20 and out["dtype"] == "f32"
+    assert r["traffic"] is not None and abs(r["launch_ms"] - 20 * r["kernel_ms"]) < 1e-9
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
