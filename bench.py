@@ -131,7 +131,7 @@ def _update_path(alg, world=1):
         return "torch autograd"
     if getattr(tr, "has_fused_minibatch", False):
         return ("lg_ppo_minibatch: forward + PPO loss + backward in one f32-MFMA kernel (v_mfma_f32_16x16x4_f32), lg_adam_step; "
-                + ("one HIP graph per update" if world == 1 else "eager launches with one flat all-reduce between the backward and the optimiser step"))
+                + ("one HIP graph per update" if world == 1 else "per mini-batch step: [backward HIP graph] -> one flat all-reduce (eager) -> [optimiser HIP graph]"))
     return ("wide learner kernels: chain forward k_mlp_chain_fwd64 + tiled dX / dW GEMMs (ds_read_b64_tr_b16 operand staging), split-bf16 products (hi*hi + hi*lo + lo*hi, f32 accumulate) "
             "on v_mfma_f32_32x32x16_bf16 (lg_mlp_wide_set_precision(1), the default; 0 = f32 MFMA), lg_ppo_loss, lg_adam_step")
 
@@ -484,6 +484,7 @@ def training_leg(a, iters, rank, local_rank, world, coll_dev, ranks_seen, backen
             coll = {"all_gather_returns_advantages": 1, "gradient_all_reduce": steps, "kl_all_reduce": steps if alg.schedule == "adaptive" else 0}
         coll.update({"backend": "nccl (RCCL)" if backend == "nccl" else backend, "ranks": ranks_seen})
         out["collectives_per_iteration"] = coll
+        out["host_launches_per_update"] = getattr(alg, "dp_launches", None) or {"note": "eager kernel launches (two-graph capture not used: " + str(getattr(alg, "_dp_graph_error", "torch MLP path")) + ")"}
     return out
 
 

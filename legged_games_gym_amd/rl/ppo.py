@@ -1,5 +1,7 @@
 """PPO with GAE, clipped surrogate / value losses and the adaptive-KL learning rate
 (hyper-parameters: reference ``legged_robot_config.py:215-228``)."""
+import os
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -380,11 +382,14 @@ class PPO:
         else:
             torch.autograd.backward([mu, val], [d_mu, d_val])
 
-    def _mb_step_fused(self):
+    def _mb_step_fused(self, phase=None):
         """Mini-batch step on the device kernels: [MLP forward -> PPO loss -> MLP backward] -> gradient clip + KL rule + Adam.
         The bracket is ONE kernel (lg_ppo_minibatch) when the networks have the learner kernels' shape; otherwise torch MLP
-        passes (autograd) around lg_ppo_loss."""
+        passes (autograd) around lg_ppo_loss.  ``phase`` (data-parallel kernel path): "pre" = everything in front of the flat
+        all-reduce, "post" = everything behind it -- the two halves are captured as HIP graphs around the eager collective."""
         st, ac, ix = self.storage, self.actor_critic, self._ix
+        if phase == "post":
+            return self._mb_step_fused_post(self.desired_kl is not None and self.schedule == "adaptive", self._dp_acc_done, True)
         flat_dp = _world() > 1 and self._mlp_kernels
         if flat_dp:
             self._flat_grad_views()                  # .grad tensors = views of one buffer (before the descriptors read their addresses)
@@ -413,6 +418,13 @@ class PPO:
             acc_done = False
         ac.std.grad = self._d_std
         adaptive = self.desired_kl is not None and self.schedule == "adaptive"
+        if phase == "pre":
+            if not flat_dp:
+                raise RuntimeError("the two-graph data-parallel step needs the flat-gradient kernel path")
+            self._dp_acc_done = acc_done
+            if adaptive:
+                self._gflat[-1:].copy_(self._stats[2:3])
+            return
         if flat_dp:                                  # data-parallel ranks: mean gradient and mean KL (rollout shards are equal-sized), ONE collective
             self._allreduce_flat(adaptive)
         elif _world() > 1:
@@ -420,6 +432,16 @@ class PPO:
             if adaptive:
                 dist.all_reduce(self._stats[2:3], op=dist.ReduceOp.SUM)
                 self._stats[2:3] /= _world()
+        self._mb_step_fused_post(adaptive, acc_done, False)
+
+    def _mb_step_fused_post(self, adaptive, acc_done, after_collective):
+        """Behind the gradients (and the collective): [mean over ranks] -> gradient clip + KL rule + Adam."""
+        ac = self.actor_critic
+        p = lambda t: t.data_ptr()
+        if after_collective:                         # the eager all-reduce summed the flat buffer (gradients + KL slot)
+            self._gflat.mul_(1.0 / _world())
+            if adaptive:
+                self._stats[2:3].copy_(self._gflat[-1:])
         table = self._adam_table() if self._adam_kernel else None
         if table is not None:
             g = self.optimizer.param_groups[0]
@@ -556,23 +578,68 @@ class PPO:
         return mean_v, mean_s
 
     def _update_fused_eager(self, perm=None):
-        """world_size > 1: the kernel mini-batch step (learner kernels / fused loss / lg_adam_step) launched eagerly, with the
-        gradient and KL all-reduces between backward and the optimiser step (collectives are not captured into a graph)."""
+        """world_size > 1, kernel path.  A mini-batch step is [backward graph] -> flat all-reduce (RCCL, eager: one collective of all
+        gradients + the KL slot) -> [optimiser graph]: after an eager first update the two halves are captured once -- one "pre" graph
+        per mini-batch slot (each reads its own slice of the permutation buffer), one "post" graph (mean over ranks, clip, KL rule,
+        Adam) -- so an update is 2 x epochs x mini-batches graph replays + epochs x mini-batches collectives from the host, no kernel
+        launch of its own.  ``LG_DP_GRAPHS=0`` keeps the eager launches (A/B, and the fallback when capture is refused)."""
         st = self.storage
         B = st.num_envs * st.num_transitions_per_env
         mb = B // self.num_mini_batches
-        if not hasattr(self, "_ix") or self._ix.numel() != mb:
-            self._ix = torch.zeros(mb, dtype=torch.int64, device=self.device)
+        nmb = self.num_mini_batches
+        if getattr(self, "_perm_buf", None) is None or self._perm_buf.numel() != nmb * mb:
+            self._perm_buf = torch.zeros(nmb * mb, dtype=torch.int64, device=self.device)
             self._acc = torch.zeros(2, device=self.device)
+            self._dp_graphs = None
+        key = (st.observations.data_ptr(), st.advantages.data_ptr(), st.returns.data_ptr(), mb)
+        if getattr(self, "_dp_key", None) != key:
+            self._dp_key, self._dp_graphs = key, None
         self._acc.zero_()
         if perm is None:
-            perm = torch.randperm(self.num_mini_batches * mb, device=self.device)
-        for _ in range(self.num_learning_epochs):
-            for i in range(self.num_mini_batches):
-                self._ix.copy_(perm[i * mb:(i + 1) * mb])
-                self._zero_grad()
-                self._mb_step()
-        n = self.num_learning_epochs * self.num_mini_batches
+            perm = torch.randperm(nmb * mb, device=self.device)
+        self._perm_buf.copy_(perm[:nmb * mb])
+        views = [self._perm_buf[i * mb:(i + 1) * mb] for i in range(nmb)]
+        want_graphs = os.environ.get("LG_DP_GRAPHS", "1") != "0" and self._mlp_kernels and self._adam_kernel
+        self.dp_launches = None
+        if want_graphs and self._updates_done >= 1 and getattr(self, "_dp_graphs", None) is None:
+            try:
+                self._ix = views[0]
+                if self._mlp_trainer() is None:
+                    raise RuntimeError("no learner kernels for these networks")
+                if not hasattr(self, "_gstream"):
+                    self._gstream = torch.cuda.Stream(device=self.device)
+                self._gstream.wait_stream(torch.cuda.current_stream(self.device))
+                pre = []
+                for i in range(nmb):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=self._gstream):
+                        self._ix = views[i]
+                        self._zero_grad()
+                        self._mb_step_fused("pre")
+                    pre.append(g)
+                post = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(post, stream=self._gstream):
+                    self._mb_step_fused("post")
+                self._dp_graphs = (pre, post)
+            except Exception as exc:                  # capture refused (e.g. the torch MLP path): stay eager, say so once
+                self._dp_graphs = False
+                self._dp_graph_error = f"{type(exc).__name__}: {exc}"
+        if getattr(self, "_dp_graphs", None):
+            pre, post = self._dp_graphs
+            for _ in range(self.num_learning_epochs):
+                for i in range(nmb):
+                    pre[i].replay()
+                    dist.all_reduce(self._gflat, op=dist.ReduceOp.SUM)
+                    post.replay()
+            n = self.num_learning_epochs * nmb
+            self.dp_launches = {"graph_replays": 2 * n, "collectives": n, "kernel_launches_from_host": 0}
+        else:
+            for _ in range(self.num_learning_epochs):
+                for i in range(nmb):
+                    self._ix = views[i]
+                    self._zero_grad()
+                    self._mb_step()
+        n = self.num_learning_epochs * nmb
         mean_v, mean_s, lr = (float(x) for x in torch.cat((self._acc / n, self._lr.view(1))).cpu())
         self.learning_rate = lr
         self._updates_done += 1

@@ -83,7 +83,8 @@ def test_bench_under_the_drivers_launcher():
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["gloo_ranks"] == 2 and out["scaling"] == "weak" and out["value"] > 0
-    assert out["ppo_training"]["collectives_per_iteration"]["ranks"] == 2 and "eager launches" in out["ppo_training"]["update_path"]
+    assert out["ppo_training"]["collectives_per_iteration"]["ranks"] == 2 and "[optimiser HIP graph]" in out["ppo_training"]["update_path"]
+    assert out["ppo_training"]["host_launches_per_update"] == {"graph_replays": 40, "collectives": 20, "kernel_launches_from_host": 0}
 
 
 @pytest.mark.parametrize("task", ["anymal_c_rough", "cassie"])

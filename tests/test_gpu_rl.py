@@ -348,7 +348,7 @@ def _dp_worker(rank, world, port, out, obs=48, hidden=(128, 64, 32)):
         alg.update(perm=perm)
         snaps.append([p.detach().cpu().clone() for p in alg.actor_critic.parameters()] + [torch.tensor(alg.learning_rate)])
     used_flat = getattr(alg, "_gflat", None) is not None and alg._mlp is not None
-    torch.save({"snaps": snaps, "flat": used_flat}, f"{out}/r{rank}.pt")
+    torch.save({"snaps": snaps, "flat": used_flat, "launches": alg.dp_launches, "graph_error": getattr(alg, "_dp_graph_error", None)}, f"{out}/r{rank}.pt")
     dist.destroy_process_group()
 
 
@@ -365,6 +365,8 @@ def test_data_parallel_kernel_update_two_ranks_one_gpu(tmp_path, obs, hidden):
     mp.spawn(_dp_worker, args=(2, port, str(tmp_path), obs, hidden), nprocs=2, join=True)
     r0 = torch.load(tmp_path / "r0.pt", weights_only=True); r1 = torch.load(tmp_path / "r1.pt", weights_only=True)
     assert r0["flat"] and r1["flat"]                                     # the kernel path with the flat gradient buffer was the one that ran
+    # updates 2..4 ran as [backward graph] -> eager flat all-reduce -> [optimiser graph]: no kernel launch from the host
+    assert r0["graph_error"] is None and r0["launches"] == {"graph_replays": 2, "collectives": 1, "kernel_launches_from_host": 0}, (r0["graph_error"], r0["launches"])
     for a, b in zip(r0["snaps"], r1["snaps"]):
         for x, y in zip(a, b):
             assert torch.equal(x, y)
