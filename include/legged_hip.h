@@ -353,6 +353,24 @@ typedef struct lg_rollout_step {
 /* Store the transition and update the episode statistics in one launch.  Asynchronous, capturable. */
 int  lg_rollout_record(const lg_rollout_step *step, void *stream);
 
+/* The same bookkeeping for a whole segment that lg_rollout_policy wrote straight into the rollout storage (observations, actions,
+ * means, rewards, dones are already in place): the broadcast std and log N(action; mean, std) of every transition, the 0/1 time-out
+ * floats PPO bootstraps with, and the episode statistics (each env's transitions walked in step order) -- ONE launch per segment
+ * instead of one lg_rollout_record per step.  Arrays are [steps][N][...] as lg_rollout_buffers.  Asynchronous, capturable. */
+typedef struct lg_rollout_post {
+    const float   *actions, *mean;    /* [steps][N][num_actions] */
+    const float   *rewards;           /* [steps][N] */
+    const uint8_t *dones, *time_outs; /* [steps][N]; time_outs may be NULL */
+    const float   *std;               /* [num_actions] */
+    float   *sigma;                   /* out [steps][N][num_actions] */
+    float   *log_prob;                /* out [steps][N] */
+    float   *time_outs_f;             /* out [steps][N] 0/1, may be NULL */
+    float   *cur_return, *cur_length; /* [N] running episode return / length, may both be NULL */
+    float   *sums;                    /* [3] += {return, length, 1} of every episode that ended inside the segment */
+    int32_t  steps, num_envs, num_actions;
+} lg_rollout_post;
+int  lg_rollout_finish(const lg_rollout_post *post, void *stream);
+
 /* One parameter tensor of torch.optim.Adam(capturable=True): the parameter, its .grad and the optimiser state
  * (state['exp_avg'], state['exp_avg_sq'], state['step'] -- a float32 device scalar).  All updated in place. */
 typedef struct lg_adam_tensor {

@@ -203,6 +203,12 @@ class lg_rollout_step(C.Structure):
                                           "sums", "std", "storage_sigma", "storage_log_prob")] + [("num_envs", i32), ("num_obs", i32), ("num_actions", i32)]
 
 
+class lg_rollout_post(C.Structure):
+    """include/legged_hip.h: lg_rollout_post."""
+    _fields_ = [(n, C.c_void_p) for n in ("actions", "mean", "rewards", "dones", "time_outs", "std", "sigma", "log_prob", "time_outs_f",
+                                          "cur_return", "cur_length", "sums")] + [("steps", i32), ("num_envs", i32), ("num_actions", i32)]
+
+
 class lg_adam_tensor(C.Structure):
     """include/legged_hip.h: lg_adam_tensor."""
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("step", C.c_void_p),
@@ -278,6 +284,7 @@ def bind_prototypes(lib, prefix: str):
         lib.lg_ppo_minibatch.restype = C.c_int
         lib.lg_adam_step.argtypes = [C.POINTER(lg_adam_tensor), i32, vp, C.c_float, C.c_float, C.c_float, C.c_float, vp, C.c_float, vp, vp]
         lib.lg_adam_step.restype = C.c_int
+        lib.lg_rollout_finish.argtypes, lib.lg_rollout_finish.restype = [C.POINTER(lg_rollout_post), vp], C.c_int
         lib.lg_rollout_record.argtypes = [C.POINTER(lg_rollout_step), vp]
         lib.lg_rollout_record.restype = C.c_int
         lib.lg_mlp_trace.argtypes, lib.lg_mlp_trace.restype = [vp], None
@@ -302,7 +309,7 @@ EXPORTED_SYMBOLS = ["lg_create", "lg_destroy", "lg_bind", "lg_step", "lg_reset_i
                     "lg_abi_version", "lg_sizeof", "lg_set_obs_buffer", "lg_policy_create", "lg_policy_destroy", "lg_policy_act",
                     "lg_step_policy", "lg_gae_returns", "lg_ppo_loss", "lg_policy_load_device", "lg_mlp_forward",
                     "lg_mlp_workspace_bytes", "lg_mlp_backward", "lg_mlp_wide_workspace_bytes", "lg_mlp_wide_forward", "lg_mlp_wide_backward", "lg_mlp_wide_set_precision", "lg_adam_step", "lg_rollout_record", "lg_mlp_trace", "lg_ppo_minibatch", "lg_set_deferred_extras", "lg_extras_flush",
-                    "lg_device_status", "lg_clear_device_status", "lg_debug_handover", "lg_rollout_policy"]
+                    "lg_device_status", "lg_clear_device_status", "lg_debug_handover", "lg_rollout_policy", "lg_rollout_finish"]
 
 
 def load_library():

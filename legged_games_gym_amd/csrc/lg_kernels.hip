@@ -2665,6 +2665,18 @@ int lg_rollout_record(const lg_rollout_step *s, void *stream) {
     return 0;
 }
 
+int lg_rollout_finish(const lg_rollout_post *s, void *stream) {
+    if (!s || !s->actions || !s->mean || !s->rewards || !s->dones || !s->std || !s->sigma || !s->log_prob) return fail(-1, "null argument");
+    if (s->steps <= 0 || s->num_envs <= 0 || s->num_actions <= 0 || s->num_actions > 16) return fail(-1, "bad sizes (at most 16 actions)");
+    if ((s->cur_return != nullptr) != (s->cur_length != nullptr) || (s->cur_return && !s->sums)) return fail(-1, "incomplete episode statistics");
+    lg::RollPostArgs a{s->actions, s->mean, s->rewards, s->dones, s->time_outs, s->std, s->sigma, s->log_prob, s->time_outs_f,
+                       s->cur_return, s->cur_length, s->sums, s->steps, s->num_envs, s->num_actions};
+    const int64_t n_tr = (int64_t)s->steps * s->num_envs;
+    hipLaunchKernelGGL(lg::k_rollout_post, dim3((unsigned)((n_tr * 16 + 255) / 256 + (s->num_envs + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int lg_adam_step(const lg_adam_tensor *tensors, int32_t n_tensors, float *lr, float beta1, float beta2, float eps, float max_grad_norm,
                  const float *kl, float desired_kl, float *scratch, void *stream) {
     if (!tensors || !lr || !scratch || n_tensors < 1 || n_tensors > LG_ADAM_MAX_TENSORS) return fail(-1, "bad argument");

@@ -733,4 +733,47 @@ __global__ void __launch_bounds__(256) k_rollout_record(const RecordArgs A) {
     }
 }
 
+// ---- the same bookkeeping for a whole rollout segment that lg_rollout_policy wrote straight into the storage: ONE launch ------------
+struct RollPostArgs {
+    const float *actions, *mean, *rewards; const uint8_t *dones, *time_outs;   // [T][N][A] / [T][N]
+    const float *std; float *sigma, *log_prob, *time_outs_f;                   // [A] -> [T][N][A], [T][N], [T][N] (0/1, optional)
+    float *cur_rew, *cur_len, *sums;                                            // running episode return / length [N]; {sum_rew, sum_len, count}
+    int32_t steps, num_envs, num_actions;
+};
+__global__ void __launch_bounds__(256) k_rollout_post(const RollPostArgs A) {
+    // blocks [0, nb_tr): 16 lanes per transition (t, env): lane a owns action a's log-prob term (as k_rollout_record);
+    // blocks [nb_tr, ...): one thread per env walks its T transitions in order for the episode statistics (rsl_rl's rewbuffer / lenbuffer)
+    const int64_t n_tr = (int64_t)A.steps * A.num_envs;
+    const int nb_tr = (int)((n_tr * 16 + 255) / 256);
+    if ((int)blockIdx.x < nb_tr) {
+        const int64_t t16 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        const int64_t tr_raw = t16 >> 4; const int a = (int)(t16 & 15);
+        const bool live = tr_raw < n_tr;
+        const int64_t tr = live ? tr_raw : n_tr - 1;
+        float term = 0.0f;
+        if (a < A.num_actions) {
+            const size_t j = (size_t)tr * A.num_actions + a;
+            const float sg = A.std[a], z = (A.actions[j] - A.mean[j]) / sg;
+            term = -0.5f * z * z - __logf(sg) - 0.918938533f;
+            if (live) A.sigma[j] = sg;
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) term += __shfl_xor(term, o);
+        if (live && a == 0) {
+            A.log_prob[tr] = term;
+            if (A.time_outs_f) A.time_outs_f[tr] = A.time_outs && A.time_outs[tr] ? 1.0f : 0.0f;
+        }
+        return;
+    }
+    const int env = ((int)blockIdx.x - nb_tr) * 256 + threadIdx.x;
+    if (env >= A.num_envs || !A.cur_rew) return;
+    float cr = A.cur_rew[env], cl = A.cur_len[env], s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
+    for (int t = 0; t < A.steps; t++) {
+        cr += A.rewards[(size_t)t * A.num_envs + env]; cl += 1.0f;
+        if (A.dones[(size_t)t * A.num_envs + env]) { s0 += cr; s1 += cl; s2 += 1.0f; cr = 0.0f; cl = 0.0f; }
+    }
+    A.cur_rew[env] = cr; A.cur_len[env] = cl;
+    if (s2 > 0.0f) { atomicAdd(A.sums + 0, s0); atomicAdd(A.sums + 1, s1); atomicAdd(A.sums + 2, s2); }
+}
+
 }  // namespace lg

@@ -220,16 +220,18 @@ class LeggedRobot(BaseTask):
         N, T = self.num_envs, int(steps)
         if storage is None:
             dev, f32 = self.device, torch.float32
-            storage = {"obs": torch.empty(T + 1, N, self.num_obs, device=dev, dtype=f32), "actions": torch.empty(T, N, self.num_actions, device=dev, dtype=f32),
-                       "mean": torch.empty(T, N, self.num_actions, device=dev, dtype=f32), "rew": torch.empty(T, N, device=dev, dtype=f32),
-                       "dones": torch.empty(T, N, device=dev, dtype=torch.bool), "time_outs": torch.empty(T, N, device=dev, dtype=torch.bool)}
+            with torch.inference_mode(False):         # obs_buf becomes a view of this storage: keep it usable by autograd modules
+                storage = {"obs": torch.empty(T + 1, N, self.num_obs, device=dev, dtype=f32), "actions": torch.empty(T, N, self.num_actions, device=dev, dtype=f32),
+                           "mean": torch.empty(T, N, self.num_actions, device=dev, dtype=f32), "rew": torch.empty(T, N, device=dev, dtype=f32),
+                           "dones": torch.empty(T, N, device=dev, dtype=torch.bool), "time_outs": torch.empty(T, N, device=dev, dtype=torch.bool)}
         # the first step starts from the current observations: the kernel reads them where they are (and copies them to obs[0])
         obs0 = self.obs_buf if storage["obs"][0].data_ptr() != self.obs_buf.data_ptr() else None
         if obs0 is not None and not (obs0.is_contiguous() and obs0.dtype == torch.float32):
             storage["obs"][0].copy_(obs0); obs0 = None
         self._sim.rollout_policy(fused_actor, storage, -1 if self._capturing else self.common_step_counter + 1, deterministic, obs0=obs0)
         self.common_step_counter += T
-        self.obs_buf = storage["obs"][T]
+        with torch.inference_mode(False):
+            self.obs_buf = storage["obs"][T]
         return storage
 
     def make_graphed_rollout(self, fused_actor, steps, warmup=1):

@@ -50,6 +50,7 @@ class OnPolicyRunner:
             return None
         self._time_outs = torch.zeros(self.num_steps_per_env, env.num_envs, 1, device=self.device)
         self._fused_step = None                               # decided at the first rollout: lg_step_policy or actor kernel + lg_step
+        self._rolled = None                                   # ... or the whole rollout in one launch (lg_rollout_policy)
         return fused
 
     def _fused_env_step(self, obs):
@@ -87,9 +88,50 @@ class OnPolicyRunner:
             return tr.forward(None)[0]
         return ac.evaluate(cobs)
 
+    def _rollout_steps_rolled(self, stats):
+        """The whole rollout of an iteration as ONE launch (``lg_rollout_policy``: the multi-step kernel writes observations, actions,
+        means, rewards and dones straight into the PPO storage) plus ONE bookkeeping launch (``lg_rollout_finish``: sigma, log-probs,
+        time-out floats, episode statistics).  Returns None when the sim / actor pair has no multi-step kernel."""
+        env, alg, fused = self.env, self.alg, self._fused
+        st, T = alg.storage, self.num_steps_per_env
+        N, A, dev = env.num_envs, st.actions.shape[-1], self.device
+        roll = getattr(self, "_roll", None)
+        if roll is None or roll["obs"].shape[0] != T + 1 or st.observations.data_ptr() != roll["obs"].data_ptr():
+            with torch.inference_mode(False):         # (rollouts run under inference_mode; env.obs_buf becomes a view of this buffer and callers feed it to autograd modules)
+                obs_all = torch.empty(T + 1, N, st.observations.shape[-1], device=dev)     # [T + 1]: the kernel leaves the next observations behind the stored ones
+                st.observations = obs_all[:T]                                                # (the learner kernels read the storage through this view)
+                roll = {"obs": obs_all, "actions": st.actions, "mean": st.mu, "rew": st.rewards.view(T, N), "dones": st.dones.view(T, N),
+                        "time_outs": torch.zeros(T, N, dtype=torch.uint8, device=dev)}
+            self._roll = roll
+        try:
+            env.rollout_policy(fused, T, storage=roll)
+        except RuntimeError as exc:
+            if "multi-step rollout kernel" not in str(exc):
+                raise
+            return None
+        post = capi.lg_rollout_post()
+        p = lambda x: x.data_ptr()
+        post.actions, post.mean, post.rewards, post.dones, post.time_outs = p(st.actions), p(st.mu), p(st.rewards), p(st.dones), p(roll["time_outs"])
+        post.std, post.sigma, post.log_prob, post.time_outs_f = p(alg.actor_critic.std), p(st.sigma), p(st.actions_log_prob), p(self._time_outs)
+        post.cur_return, post.cur_length, post.sums = p(stats["cur_rew"]), p(stats["cur_len"]), p(stats["_sums"])
+        post.steps, post.num_envs, post.num_actions = T, N, A
+        rc = fused.lib.lg_rollout_finish(post, torch.cuda.current_stream(self.device).cuda_stream)
+        if rc != 0:
+            raise RuntimeError(f"lg_rollout_finish failed ({rc}): {fused.lib.lg_last_error().decode()}")
+        st.step = T
+        st.values.copy_(self._critic_values(st).view(T, -1, 1))
+        st.rewards.add_(alg.gamma * st.values * self._time_outs)
+        obs = env.obs_buf
+        return obs, obs
+
     def _rollout_steps_fused(self, stats):
         env, alg, fused = self.env, self.alg, self._fused
         st, T = alg.storage, self.num_steps_per_env
+        if self._rolled is not False and "_sums" in stats and self.cfg.get("rolled_rollout", True):
+            out = self._rollout_steps_rolled(stats)
+            self._rolled = out is not None
+            if out is not None:
+                return out
         obs = env.get_observations()
         lib, step = fused.lib, capi.lg_rollout_step()
         p = lambda x: x.data_ptr()

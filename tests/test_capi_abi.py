@@ -34,7 +34,7 @@ def test_hip_library_exports_all_symbols_and_layouts():
 
 def test_oracle_exports_same_abi(oracle_lib):
     for sym in _declared_functions():
-        if sym.startswith(("lg_policy_", "lg_mlp_")) or sym in ("lg_step_policy", "lg_rollout_policy", "lg_gae_returns", "lg_ppo_loss", "lg_ppo_minibatch", "lg_adam_step", "lg_rollout_record"):
+        if sym.startswith(("lg_policy_", "lg_mlp_")) or sym in ("lg_step_policy", "lg_rollout_policy", "lg_gae_returns", "lg_ppo_loss", "lg_ppo_minibatch", "lg_adam_step", "lg_rollout_record", "lg_rollout_finish"):
             continue          # learner-side kernels: their reference is torch fp32 (forward / autograd), not the C oracle
         if sym in ("lg_set_deferred_extras", "lg_extras_flush", "lg_device_status", "lg_clear_device_status", "lg_debug_handover"):
             continue          # launch scheduling / wave hand-over status of the device library: nothing to restate on the CPU
