@@ -1802,6 +1802,7 @@ __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
                 A.prof[LG_NPROF + LG_NPROF_BLOCKS * 40 + (size_t)(rt + 1) * LG_NPROF_BLOCKS + blockIdx.x] = wall_clock64();
 #endif
         }
+        LG_PROF_END(PF_EXTRAS, A.prof);
         return;                    // extras["episode"] and the step counter: k_roll_finish, behind this launch
     } else one_step(0);
     const int64_t step = step0;
