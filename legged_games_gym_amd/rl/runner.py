@@ -75,16 +75,29 @@ class OnPolicyRunner:
         ac = self.alg.actor_critic
         cobs = (st.privileged_observations if st.privileged_observations is not None else st.observations).flatten(0, 1)
         tr = getattr(self, "_critic_fwd", None)
-        if tr is None or (tr is not False and (tr.inputs[0].data_ptr() != cobs.data_ptr() or tr.mb != cobs.shape[0])):
+        if tr is None or (tr is not False and (tr.inputs[0].data_ptr() != cobs.data_ptr() or tr.mb * len(getattr(self, "_critic_chunks", None) or [0]) != cobs.shape[0])):
             from .mlp_kernels import MlpTrainer, WideMlpTrainer
             tr = False
+            self._critic_chunks = None
             if isinstance(ac.critic, torch.nn.Sequential) and cobs.is_cuda:
                 tr = MlpTrainer([ac.critic], [cobs], cobs.shape[0], forward_only=True)
                 if not tr.supported:                  # the 512-256-128 critics: the chain forward of the wide learner kernels
-                    tr = WideMlpTrainer([ac.critic], [cobs], cobs.shape[0], forward_only=True)
+                    # in row chunks of a mini-batch: the wide workspace is sized for TRAINING on `mb` rows (activations, gradient slabs, dW
+                    # partials: 0.8 GB for all 24 x 4096 rows, 6.4 GB at 32 768 envs) although a forward needs none of the gradient regions
+                    rows_all = cobs.shape[0]
+                    parts = next((c for c in (4, 3, 2) if rows_all % c == 0 and rows_all // c >= 4096), 1)
+                    tr = WideMlpTrainer([ac.critic], [cobs], rows_all // parts, forward_only=True)
+                    if tr.supported and parts > 1:
+                        self._critic_chunks = [torch.arange(i * (rows_all // parts), (i + 1) * (rows_all // parts), device=cobs.device) for i in range(parts)]
+                        self._critic_out = torch.empty(rows_all, 1, device=cobs.device)
             self._critic_fwd = tr
         if tr is not False and tr.supported:
             tr.refresh()                              # parameter addresses (stable; the values follow the optimiser)
+            if getattr(self, "_critic_chunks", None):
+                n = self._critic_chunks[0].numel()
+                for i, rows in enumerate(self._critic_chunks):
+                    self._critic_out[i * n:(i + 1) * n].copy_(tr.forward(rows)[0])
+                return self._critic_out
             return tr.forward(None)[0]
         return ac.evaluate(cobs)
 

@@ -44,6 +44,28 @@ os.makedirs(OUT, exist_ok=True)
 # (``reference_sha256``) and re-checked by tests/test_golden_provenance.py whenever /root/reference is present
 EXECUTED = {}
 
+# What executed reference text may reach of Python's builtins: arithmetic / container helpers and class construction -- no import, open,
+# eval / exec / compile, no attribute escape hatches beyond the getattr / setattr / dir the reference's own helpers use.
+import builtins as _b
+SAFE_BUILTINS = {k: getattr(_b, k) for k in (
+    "abs", "all", "any", "bool", "dict", "dir", "enumerate", "float", "getattr", "hasattr", "int", "isinstance", "issubclass", "len", "list", "max", "min",
+    "object", "print", "range", "reversed", "round", "set", "setattr", "sorted", "str", "sum", "super", "tuple", "type", "zip", "property", "staticmethod",
+    "classmethod", "__build_class__", "NameError", "ValueError", "AttributeError", "NotImplementedError", "Exception", "True", "False", "None")
+    if hasattr(_b, k)}
+
+
+def _restricted_import(name, globals=None, locals=None, fromlist=(), level=0):
+    """`import` inside executed reference text: only the synthetic packages registered in sys.modules by load_reference_configs (and numpy / torch)."""
+    root = name.split(".")[0]
+    if level > 0 and str((globals or {}).get("__name__", "")).startswith("legged_gym"):      # relative import between the synthetic config modules
+        return _b.__import__(name, globals, locals, fromlist, level)
+    if root in ("legged_gym", "numpy", "torch", "math", "inspect") and (name in sys.modules or root in ("numpy", "torch", "math", "inspect")):
+        return _b.__import__(name, globals, locals, fromlist, level)
+    raise ImportError(f"import of '{name}' from executed reference text is not allowed")
+
+
+SAFE_BUILTINS["__import__"] = _restricted_import
+
 
 def read_reference(rel):
     import hashlib
@@ -87,6 +109,7 @@ def load_reference_configs():
     def run(name, rel):
         path, text = read_reference(rel)
         m = mod(name, path)
+        m.__dict__["__builtins__"] = SAFE_BUILTINS
         exec(compile(text, path, "exec"), m.__dict__)
         return m
     for pkg in ("legged_gym", "legged_gym.envs", "legged_gym.envs.base", "legged_gym.envs.anymal_c",
@@ -198,6 +221,7 @@ def _ref_functions(rel, class_name, namespace, want=None):
             for a in node.args.args + node.args.kwonlyargs:
                 a.annotation = None                    # type hints name classes that are not importable here
             scope = dict(namespace)
+            scope["__builtins__"] = SAFE_BUILTINS
             exec(compile(ast.Module(body=[node], type_ignores=[]), path, "exec"), scope)
             fn = scope[node.name]
             fn.__globals__.update(namespace)          # see the shared helpers (and each other) at call time
