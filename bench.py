@@ -209,8 +209,12 @@ def worker(a):
 
     fused_step = False                                    # actor fused INTO the step kernel (lg_step_policy): flat actor only
     rollout_kernel = False                                # ... and G steps per launch (lg_rollout_policy)
-    G = max(g for g in range(1, max(1, a.graph_steps) + 1) if a.steps % g == 0 and a.warmup % g == 0)      # policy steps per graph replay / per rollout launch
+    # policy steps per graph replay / per rollout launch: a divisor of the TIMED step count only; the part of the warm-up that is not a
+    # multiple of it runs as eager single steps first (the driver's `--steps 20 --warmup 5` then still times ONE 20-step launch per region)
+    G = max(g for g in range(1, max(1, a.graph_steps) + 1) if a.steps % g == 0)
     with torch.inference_mode():
+        for _ in range(a.warmup % G):
+            env.step(policy_act(env.obs_buf))
         if not use_torch and not a.no_fused_step:
             try:
                 if not a.no_rollout and G > 1:
