@@ -194,6 +194,10 @@ int  lg_actuator_forward(lg_sim *sim, const float *pos_err, const float *vel, fl
                          float *hidden, float *cell, int32_t rows, void *stream);       /* anymal.py:71-78 */
 int  lg_physics_substep(lg_sim *sim, const float *torques, int32_t write_contacts, void *stream); /* legged_robot.py:92-96 */
 int  lg_compute_observations_only(lg_sim *sim, int64_t common_step_counter, void *stream);        /* legged_robot.py:212-230 */
+/* reset_idx evaluates update_command_curriculum BEFORE _resample_commands (legged_robot.py:159-176).  The fused step resets inside the
+ * launch; when the host rule then widened the ranges (lg_set_params), this re-draws the commands of the envs whose reset_buf the step set
+ * from the new ranges -- same Philox block as the in-step draw -- and patches the command slots of the bound observation buffer. */
+int  lg_resample_reset_commands(lg_sim *sim, int64_t common_step_counter, void *stream);
 
 /* Redirect where the next lg_step / lg_compute_observations_only writes observations ([N,num_obs] device buffer).
  * The reference re-creates obs_buf every step (legged_robot.py:215) and rsl_rl keeps a reference to the previous

@@ -290,6 +290,7 @@ def bind_prototypes(lib, prefix: str):
         lib.lg_mlp_trace.argtypes, lib.lg_mlp_trace.restype = [vp], None
         lib.lg_set_deferred_extras.argtypes, lib.lg_set_deferred_extras.restype = [vp, i32], C.c_int
         lib.lg_extras_flush.argtypes, lib.lg_extras_flush.restype = [vp, i64, vp], C.c_int
+        lib.lg_resample_reset_commands.argtypes, lib.lg_resample_reset_commands.restype = [vp, i64, vp], C.c_int
         lib.lg_device_status.argtypes, lib.lg_device_status.restype = [vp, i32], C.c_int
         lib.lg_clear_device_status.argtypes, lib.lg_clear_device_status.restype = [vp], C.c_int
         lib.lg_debug_handover.argtypes, lib.lg_debug_handover.restype = [vp, i32, i32], C.c_int
@@ -309,7 +310,7 @@ EXPORTED_SYMBOLS = ["lg_create", "lg_destroy", "lg_bind", "lg_step", "lg_reset_i
                     "lg_abi_version", "lg_sizeof", "lg_set_obs_buffer", "lg_policy_create", "lg_policy_destroy", "lg_policy_act",
                     "lg_step_policy", "lg_gae_returns", "lg_ppo_loss", "lg_policy_load_device", "lg_mlp_forward",
                     "lg_mlp_workspace_bytes", "lg_mlp_backward", "lg_mlp_wide_workspace_bytes", "lg_mlp_wide_forward", "lg_mlp_wide_backward", "lg_mlp_wide_set_precision", "lg_adam_step", "lg_rollout_record", "lg_mlp_trace", "lg_ppo_minibatch", "lg_set_deferred_extras", "lg_extras_flush",
-                    "lg_device_status", "lg_clear_device_status", "lg_debug_handover", "lg_rollout_policy", "lg_rollout_finish"]
+                    "lg_device_status", "lg_clear_device_status", "lg_debug_handover", "lg_rollout_policy", "lg_rollout_finish", "lg_resample_reset_commands"]
 
 
 def load_library():
@@ -401,6 +402,9 @@ class Sim:
     def set_params(self, params: lg_params):
         self.params = params
         self._check(self._fn("set_params")(self.handle, C.byref(params)))
+
+    def resample_reset_commands(self, common_step_counter: int, stream: int = 0):
+        self._check(self.lib.lg_resample_reset_commands(self.handle, int(common_step_counter), stream))
 
     def device_status(self, synchronize: bool = True) -> int:
         """``lg_device_status``: the sticky status word of the handle (0 = clean); see include/legged_hip.h."""

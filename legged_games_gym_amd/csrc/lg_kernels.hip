@@ -2023,6 +2023,26 @@ __global__ void __launch_bounds__(LG_BLOCK) k_obs(const KArgs A) {
     write_observations<T>(A, e, k, live, A.step, root, q, qd, act, tab, blv, bav, pg, cmd, true);
 }
 
+// reset_idx calls update_command_curriculum BEFORE _resample_commands (legged_robot.py:159-176): when the host widened the command ranges on a
+// curriculum tick, the envs this step reset re-draw their commands from the NEW ranges -- same Philox block as the in-step draw (seed; env,
+// step, CMD_RESET), so only the ranges differ -- and the command slots of the step's observations follow (their noise scale is 0, :500).
+__global__ void __launch_bounds__(256) k_resample_reset(const KArgs A) {
+    const lg_params &P = A.P; const lg_buffers &B = A.B;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= P.num_envs || !B.reset_buf[e]) return;
+    float u[4], cmd[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) cmd[i] = B.commands[(size_t)e * 4 + i];
+    rand4(P.seed, e, A.step, RNG_CMD_RESET, 0, u);
+    resample_commands_u(P, u, cmd);
+#pragma unroll
+    for (int i = 0; i < 4; i++) B.commands[(size_t)e * 4 + i] = cmd[i];
+    float *obs = B.obs_buf + (size_t)e * P.num_obs;
+    const float c = P.clip_observations;
+    obs[9] = fminf(fmaxf(cmd[0] * P.obs_scale_lin_vel, -c), c); obs[10] = fminf(fmaxf(cmd[1] * P.obs_scale_lin_vel, -c), c);
+    obs[11] = fminf(fmaxf(cmd[2] * P.obs_scale_ang_vel, -c), c);
+}
+
 // ====================================================================  host side: C-ABI  ====================================================================
 static thread_local char g_err[512] = "";
 static int fail(int code, const char *fmt, const char *arg = "") { snprintf(g_err, sizeof g_err, fmt, arg); return code; }
@@ -3261,6 +3281,16 @@ int lg_physics_substep(lg_sim *s, const float *torques, int32_t write_contacts, 
         if (hf) hipLaunchKernelGGL((k_physics<CassieTraits, true>), g, b, 0, st, a, torques, write_contacts);
         else hipLaunchKernelGGL((k_physics<CassieTraits, false>), g, b, 0, st, a, torques, write_contacts);
     }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int lg_resample_reset_commands(lg_sim *s, int64_t common_step_counter, void *stream) {
+    if (!s || !s->bound) return fail(-8, "lg_bind has not been called");
+    if (int rc = status_error(s)) return rc;
+    if (common_step_counter < 0) return fail(-9, "lg_resample_reset_commands needs the step's counter (the Philox key of its reset draws)");
+    KArgs a; fill_args(s, a, common_step_counter);
+    hipLaunchKernelGGL(k_resample_reset, dim3((s->P.num_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }

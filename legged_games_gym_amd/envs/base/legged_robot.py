@@ -120,6 +120,8 @@ class LeggedRobot(BaseTask):
         if new != list(self.command_ranges["lin_vel_x"]):
             self.command_ranges["lin_vel_x"][:] = new
             self.set_command_ranges()
+            # reference order (:159-176): the envs this step reset draw their commands AFTER the widening
+            self._sim.sim.resample_reset_commands(self.common_step_counter, torch.cuda.current_stream(self.device).cuda_stream)
         self.extras["episode"]["max_command_x"] = self.command_ranges["lin_vel_x"][1]
 
     def begin_graph_capture(self):

@@ -36,7 +36,7 @@ def test_oracle_exports_same_abi(oracle_lib):
     for sym in _declared_functions():
         if sym.startswith(("lg_policy_", "lg_mlp_")) or sym in ("lg_step_policy", "lg_rollout_policy", "lg_gae_returns", "lg_ppo_loss", "lg_ppo_minibatch", "lg_adam_step", "lg_rollout_record", "lg_rollout_finish"):
             continue          # learner-side kernels: their reference is torch fp32 (forward / autograd), not the C oracle
-        if sym in ("lg_set_deferred_extras", "lg_extras_flush", "lg_device_status", "lg_clear_device_status", "lg_debug_handover"):
+        if sym in ("lg_set_deferred_extras", "lg_extras_flush", "lg_device_status", "lg_clear_device_status", "lg_debug_handover", "lg_resample_reset_commands"):
             continue          # launch scheduling / wave hand-over status of the device library: nothing to restate on the CPU
         assert hasattr(oracle_lib, "lgo_" + sym[3:]), sym
     assert oracle_lib.lgo_abi_version() == capi.LG_ABI_VERSION

@@ -428,3 +428,48 @@ def test_runner_rolled_rollout_fills_the_storage_like_the_per_step_rollout():
         else:
             scale = max(1.0, float(a[k].abs().max()))
             assert float((a[k] - b[k]).abs().max()) < 1e-4 * scale, (k, float((a[k] - b[k]).abs().max()))
+
+
+def test_command_curriculum_tick_resamples_the_reset_envs_from_the_widened_range():
+    """reset_idx applies update_command_curriculum BEFORE _resample_commands (legged_robot.py:159-176): on a curriculum tick that widens
+    lin_vel_x, the envs the fused step reset re-draw their commands from the new range (same Philox block: u is unchanged, the range is not),
+    the command slots of their observations follow, and extras carries max_command_x."""
+    import numpy as np
+    from tests import philox_np as ph
+    from legged_games_gym_amd.envs import task_registry
+    from legged_games_gym_amd.utils import get_args
+    N = 256
+    args = get_args(["--task", "anymal_c_flat", "--num_envs", str(N), "--headless", "--sim_device", "cuda:0", "--rl_device", "cuda:0"])
+    env_cfg, _ = task_registry.get_cfgs("anymal_c_flat")
+    env_cfg.commands.curriculum, env_cfg.commands.max_curriculum = True, 2.0
+    env_cfg.commands.ranges.lin_vel_x = [-0.5, 0.5]
+    env_cfg.env.episode_length_s = 0.1                        # max_episode_length = 5: every env times out on step 6, ticks at steps 5, 10, ...
+    try:
+        env, _ = task_registry.make_env("anymal_c_flat", args, env_cfg=env_cfg)
+        env.reset()
+        act = torch.zeros(N, 12, device="cuda")
+        widened = False
+        for s in range(1, 31):
+            lo0, hi0 = env.command_ranges["lin_vel_x"]
+            # make the rule fire: the reset envs' mean tracking sum must exceed 80 % of the maximum
+            env.episode_sums["tracking_lin_vel"][:] = env.reward_scales["tracking_lin_vel"] * env.max_episode_length
+            obs, _, _, dones, extras = env.step(act)
+            torch.cuda.synchronize()
+            lo1, hi1 = env.command_ranges["lin_vel_x"]
+            if (lo1, hi1) != (lo0, hi0) and dones.any():
+                widened = True
+                ids = torch.nonzero(dones).flatten().cpu().numpy()
+                u = ph.uniforms(int(env._params.seed), ids, env.common_step_counter, ph.CMD_RESET, 0)
+                want = (hi1 - lo1) * u[:, 0] + lo1
+                keep = np.sqrt(want ** 2 + (2.0 * u[:, 1] - 1.0) ** 2) > 0.2          # lin_vel_y range is [-1, 1] in this config
+                got = env.commands[dones, 0].cpu().numpy()
+                np.testing.assert_allclose(got, want * keep, atol=1e-6)
+                assert np.abs(got).max() > max(abs(lo0), abs(hi0)) - 1e-3 or len(ids) < 20       # some draws lie outside the OLD range
+                np.testing.assert_allclose(obs[dones, 9].cpu().numpy(), got * 2.0, atol=1e-5)
+                assert abs(extras["episode"]["max_command_x"] - hi1) < 1e-9
+                break
+        assert widened
+    finally:
+        env_cfg.commands.curriculum = False
+        env_cfg.commands.ranges.lin_vel_x = [-1.0, 1.0]
+        env_cfg.env.episode_length_s = 20
