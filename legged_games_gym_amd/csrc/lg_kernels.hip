@@ -207,14 +207,28 @@ template <bool HF> LG_DEV void hf_contact(const KArgs &A, const HfFetch &f, floa
             const bool up = (h10 + h11) > (h00 + h01);
             const float top = up ? h10 + (h11 - h10) * f.ty : h00 + (h01 - h00) * f.ty;
             const float dist = (up ? 1.0f - f.tx : f.tx) * hs;
-            if (pz - radius < top) { float d = radius - dist; if (d > wall_depth) { wall_depth = d; wall_n = v3(up ? -1.0f : 1.0f, 0, 0); } }
+            if (pz - radius < top) {
+                float d = radius - dist; V3 fn = v3(up ? -1.0f : 1.0f, 0, 0);
+                if (pz > top) {              // centre above the riser's top edge: edge contact (oracle comment)
+                    const float dz = pz - top, len = sqrtf(dist * dist + dz * dz), il = 1.0f / fmaxf(len, 1e-9f);
+                    d = radius - len; fn = v3((up ? -dist : dist) * il, 0, dz * il);
+                }
+                if (d > wall_depth) { wall_depth = d; wall_n = fn; }
+            }
             if (up) { h10 = h00; h11 = h01; } else { h00 = h10; h01 = h11; }
         }
         if (fmaxf(fabsf(h01 - h00), fabsf(h11 - h10)) > thr) {
             const bool up = (h01 + h11) > (h00 + h10);
             const float top = up ? h01 + (h11 - h01) * f.tx : h00 + (h10 - h00) * f.tx;
             const float dist = (up ? 1.0f - f.ty : f.ty) * hs;
-            if (pz - radius < top) { float d = radius - dist; if (d > wall_depth) { wall_depth = d; wall_n = v3(0, up ? -1.0f : 1.0f, 0); } }
+            if (pz - radius < top) {
+                float d = radius - dist; V3 fn = v3(0, up ? -1.0f : 1.0f, 0);
+                if (pz > top) {
+                    const float dz = pz - top, len = sqrtf(dist * dist + dz * dz), il = 1.0f / fmaxf(len, 1e-9f);
+                    d = radius - len; fn = v3(0, (up ? -dist : dist) * il, dz * il);
+                }
+                if (d > wall_depth) { wall_depth = d; wall_n = fn; }
+            }
             if (up) { h01 = h00; h11 = h10; } else { h00 = h01; h10 = h11; }
         }
     }

@@ -242,8 +242,10 @@ static inline float hf_at(const lgo_sim *s, int ix, int iy) {
  * hands the same int16 grid to PhysX, legged_robot.py:619-637).
  * hf_step_threshold > 0 ('trimesh', terrain.py:69-73: slopes above slope_treshold are "corrected to vertical surfaces" when the
  * samples are triangulated): along an axis whose height difference across the cell exceeds the threshold, the ramp is replaced
- * by the LOW side's level up to a vertical face at the HIGH side of the cell; a sphere below the top of that face and within
- * reach of it touches the face with a horizontal normal.  The deepest of {ground, x-face, y-face} is the point's contact. */
+ * by the LOW side's level up to a vertical face at the HIGH side of the cell; a sphere whose centre is below the top of that face and
+ * within reach of it touches the face with a horizontal normal, one whose centre is above the top touches the face's top EDGE (normal
+ * from the edge point to the centre: a foot overhanging a stair edge is carried by it instead of dropping to the lower level).  The
+ * deepest of {ground, x-face / x-edge, y-face / y-edge} is the point's contact. */
 static void ground_contact(const lgo_sim *s, float x, float y, float pz, float radius, float *depth, v3 *n) {
     if (s->P.terrain_type == LG_TERRAIN_PLANE || !s->B.height_samples) { *n = V(0, 0, 1); *depth = radius - pz; return; }
     float inv = 1.0f / s->P.hf_horizontal_scale;
@@ -263,14 +265,28 @@ static void ground_contact(const lgo_sim *s, float x, float y, float pz, float r
             const int up = (h10 + h11) > (h00 + h01);              /* rising towards +x */
             const float top = up ? h10 + (h11 - h10) * ty : h00 + (h01 - h00) * ty;       /* level behind the face (y-interpolated) */
             const float dist = (up ? 1.0f - tx : tx) * hs;         /* horizontal distance to the face */
-            if (pz - radius < top) { float d = radius - dist; if (d > wall_depth) { wall_depth = d; wall_n = V(up ? -1.0f : 1.0f, 0, 0); } }
+            if (pz - radius < top) {
+                float d = radius - dist; v3 fn = V(up ? -1.0f : 1.0f, 0, 0);
+                if (pz > top) {              /* centre above the riser's top edge: the sphere touches the EDGE, normal from the edge point to the centre */
+                    const float dz = pz - top, len = sqrtf(dist * dist + dz * dz), il = 1.0f / fmaxf(len, 1e-9f);
+                    d = radius - len; fn = V((up ? -dist : dist) * il, 0, dz * il);
+                }
+                if (d > wall_depth) { wall_depth = d; wall_n = fn; }
+            }
             if (up) { h10 = h00; h11 = h01; } else { h00 = h10; h01 = h11; }          /* the low level extends to the face */
         }
         if (fmaxf(fabsf(h01 - h00), fabsf(h11 - h10)) > thr) {
             const int up = (h01 + h11) > (h00 + h10);
             const float top = up ? h01 + (h11 - h01) * tx : h00 + (h10 - h00) * tx;
             const float dist = (up ? 1.0f - ty : ty) * hs;
-            if (pz - radius < top) { float d = radius - dist; if (d > wall_depth) { wall_depth = d; wall_n = V(0, up ? -1.0f : 1.0f, 0); } }
+            if (pz - radius < top) {
+                float d = radius - dist; v3 fn = V(0, up ? -1.0f : 1.0f, 0);
+                if (pz > top) {
+                    const float dz = pz - top, len = sqrtf(dist * dist + dz * dz), il = 1.0f / fmaxf(len, 1e-9f);
+                    d = radius - len; fn = V(0, (up ? -dist : dist) * il, dz * il);
+                }
+                if (d > wall_depth) { wall_depth = d; wall_n = fn; }
+            }
             if (up) { h01 = h00; h11 = h10; } else { h00 = h01; h10 = h11; }
         }
     }

@@ -494,3 +494,42 @@ def test_trimesh_riser_is_a_vertical_face_and_heightfield_a_ramp(oracle_lib):
     rf = hf[:, :2]                                                                          # ramp: normal (-2, 0, 1) / sqrt(5)
     ratio = np.abs(rf[..., 0]) / np.abs(rf[..., 2])
     assert (rf[..., 2] > 10.0).all() and (ratio > 1.0).all() and (ratio < 3.0).all()
+
+
+def test_foot_overhanging_a_stair_edge_is_carried_by_the_edge(oracle_lib):
+    """with 'trimesh' faces a foot sphere whose centre is beyond a stair edge by less than its radius must rest ON the edge
+    (normal from the edge point to the centre), not drop to the lower level and be pushed sideways.  Robots stand on the UPPER level of
+    the 0.2 m riser facing the drop, front foot centres 5 mm past the edge (edge normal 10 degrees off the vertical; at 15 mm it is 27
+    degrees and the viscous stick model lets the feet creep off -- with the face-only model of round 2 they dropped at any overhang);
+    twenty policy steps with zero actions (the actuator net holds the default pose)."""
+    from tests.common import robot_capsules
+    terr, cfg, robot, p, names, model, w, x_face = _riser_setup("trimesh")
+    N = 4
+    o = OracleSim(p, model, robot, w)
+    o.set_terrain(terr.heightsamples, terr.env_origins)
+    o.reset_idx(np.arange(N, dtype=np.int32), 0)
+    q0 = np.array(list(p.default_dof_pos)[:12], np.float64)
+    caps = [c for c in robot_capsules(robot, q0) if c[0] == 0]
+    centre, radius = caps[-1][1], caps[-1][3]                       # LF foot sphere in the base frame
+    top = 0.2
+    root = o.buf["root_states"]
+    root[:, :] = 0.0
+    root[:, 5] = 1.0                                                  # yaw = pi: the robot's +x (front) looks towards -x, the drop
+    over = 0.005
+    root[:, 0] = (x_face - over) + centre[0]                          # front foot centres `over` past the edge (world x = root_x - centre_x)
+    root[:, 1] = 6.0 + 2.0 * np.arange(N); root[:, 2] = top + radius - centre[2]
+    dof = o.buf["dof_state"].reshape(N, 12, 2); dof[:, :, 0] = q0.astype(np.float32); dof[:, :, 1] = 0.0
+    o.buf["contact_forces"][:] = 0.0
+    z0 = root[:, 2].copy()
+    x0 = root[:, 0].copy()
+    for s in range(1, 21):
+        o.step(np.zeros((N, 12), np.float32), s)
+        assert not o.buf["reset_buf"].any()
+    assert (np.abs(o.buf["root_states"][:, 0] - x0) < 0.02).all()    # ... and did not slide off
+    bn = list(robot.body_names)
+    front = o.buf["contact_forces"][:, [bn.index("LF_FOOT"), bn.index("RF_FOOT")], :]
+    assert (front[..., 2] > 40.0).all(), front                       # the edge carries the front feet (a quarter of 52 kg is 128 N)
+    assert (np.abs(front[..., 0]) < front[..., 2]).all()             # ... with a normal that points mostly up
+    assert (o.buf["root_states"][:, 2] > z0 - 0.06).all()            # the trunk settled on its springs, it did not sag onto the lower level (0.2 m)
+    pitch = 2.0 * (o.buf["root_states"][:, 6] * o.buf["root_states"][:, 4] - o.buf["root_states"][:, 5] * o.buf["root_states"][:, 3])
+    assert np.abs(pitch).max() < 0.1
