@@ -281,7 +281,7 @@ def worker(a):
         if fused_step and not a.no_graph:
             kern_ms_each = [1e3 * e / a.steps for e in evs]     # the timed graph IS G x k_step<..., POL>: same replays, same region
             kern_method = (f"HIP events on the launch stream around the {a.steps // G} graph replays of the timed region itself "
-                           f"(median of {repeats} regions; includes the ~1 us gaps between launches" + (f" and, per {G}-step launch, the extras finisher" if rollout_kernel else "") + ")")
+                           f"(median of {repeats} regions; includes the ~1 us gaps between launches" + ")")
         else:
             KG = 20
             fixed_actions = (policy_act(env.obs_buf) if not fused_step else fused.act(env.obs_buf)).clone()
@@ -365,7 +365,7 @@ def worker(a):
                        "envs_per_gpu": a.num_envs, "decimation": int(env.cfg.control.decimation), "sim_dt": float(env.sim_params.dt),
                        "parallelism": f"env-sharded x{world}", "state_finite": finite,
                        "launch": (f"lg_rollout_policy: ONE launch of k_step<...,POL,ROLL> per {G} policy steps (actor fused into the step, every workgroup walks through the {G} steps of its own 16 envs; "
-                                  f"per-step obs / actions / rewards / dones to rollout storage), " + ("eager launches" if a.no_graph else "replayed as a HIP graph") + " with its extras finisher") if rollout_kernel else
+                                  f"per-step obs / actions / rewards / dones to rollout storage), " + ("eager launches" if a.no_graph else "replayed as a HIP graph") + "; the last workgroup to finish publishes extras[\"episode\"]") if rollout_kernel else
                                  (("eager" if a.no_graph else f"HIP graph of {G} policy steps per replay") + (": ONE kernel per step, actor fused into the step (lg_step_policy)" if fused_step else " (policy + lg_step)")
                                   + ("" if a.no_graph or os.environ.get("LG_DEFER_EXTRAS", "1") == "0" else "; extras[\"episode\"] deferred to the next launch, one lg_extras_flush node per replay")),
                        "policy": "torch ops (hipBLASLt)" if use_torch else ("MFMA actor inside k_step (v_mfma_f32_16x16x4_f32, 4 waves)" if fused_step else "actor kernel lg_policy_act: k_policy_act_wide, 32 envs per workgroup, split-bf16 products (hi*hi + hi*lo + lo*hi, f32 accumulate) on v_mfma_f32_32x32x16_bf16")},

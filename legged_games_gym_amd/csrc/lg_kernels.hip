@@ -78,7 +78,7 @@ struct RollArgs {
     float   *actions, *mean;   // [steps][N][num_actions] (mean may be null)
     float   *rew;              // [steps][N]
     uint8_t *done, *time_outs; // [steps][N]
-    float   *extras;           // [steps][LG_NUM_REWARD_TERMS + 2] episode accumulators per step (zeroed before the launch; k_roll_finish publishes)
+    float   *extras;           // [steps][LG_NUM_REWARD_TERMS + 2] episode accumulators per step (zero at launch; roll_finish publishes and re-zeroes)
 };
 
 struct KArgs {                 // passed by value: lives in the kernarg segment -> scalar loads
@@ -1215,6 +1215,28 @@ LG_DEV void finish_extras(const KArgs &A, int t, int64_t step_used, bool publish
         A.B.episode_means[R] = acc / (float)P.num_envs;
     }
 }
+// ------------------------------------------------------------------ lg_rollout_policy: the segment's finisher
+// Run by the first wave of the workgroup that takes the LAST ticket of the multi-step launch (every other workgroup has finished all its
+// steps, so all their episode atomics are performed and all of them have read the step counter): extras["episode"] (legged_robot.py:179-188)
+// = the sums of the LAST step of the segment in which any env was reset (the dictionary stays stale otherwise, quirk Q4); the device step
+// counter moves to the last executed step; the per-step accumulators are left zeroed for the next segment.
+LG_DEV void roll_finish(const KArgs &A, int t, int64_t step0) {
+    const lg_params &P = A.P;
+    const int R = P.num_reward_slots, stride = LG_NUM_REWARD_TERMS + 2;
+    int last = -1;
+    for (int s = A.roll.steps - 1; s >= 0 && last < 0; s--)
+        if (__hip_atomic_load(A.roll.extras + (size_t)s * stride + R, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0.0f) last = s;
+    if (last >= 0 && t < R) {
+        const float v = __hip_atomic_load(A.roll.extras + (size_t)last * stride + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float c = __hip_atomic_load(A.roll.extras + (size_t)last * stride + R, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        A.B.episode_means[t] = v / c / P.max_episode_length_s;
+    }
+    if (t == 0 && A.B.step_counter) A.B.step_counter[0] = step0 + A.roll.steps - 1;
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    for (int i = t; i < A.roll.steps * stride; i += 64) __hip_atomic_store(A.roll.extras + i, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ------------------------------------------------------------------ THE fused policy-step kernel
 // One workgroup = 64 (env, limb) lanes.  A lone wave issues one instruction every ~6.5 cycles and cannot overlap its own
 // MFMA and VALU work (tools/ubench), and at 4096 envs only one wave per CU exists -- so with the actuator net the workgroup
@@ -1391,7 +1413,7 @@ template <class T, bool NET, bool HF, int NW, bool SC = false> struct HelperWave
         __syncthreads();                                           // P3: reset flags / post-reset root z / reward terms published
         if (wave == 1) {
             es.template update<T::K>(A, e, lane, sh, keeper, roll_accum ? roll_accum : accum_slot(A, step));
-            if (roll_accum) { /* rollout kernel: no ticket, no step counter -- k_roll_finish publishes after the launch */ }
+            if (roll_accum) { /* rollout kernel: no per-step ticket, no step counter -- roll_finish, behind the workgroup's last step */ }
             else {
             if (P.terrain_curriculum && A.B.terrain_levels) {      // (wave-uniform) this workgroup's share of the mean terrain level: the reset
                 // lanes' new levels were stored and drained by the rigid-body wave before P3; read past this CU's L1, which may hold the old line
@@ -1816,8 +1838,18 @@ __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
                 A.prof[LG_NPROF + LG_NPROF_BLOCKS * 40 + (size_t)(rt + 1) * LG_NPROF_BLOCKS + blockIdx.x] = wall_clock64();
 #endif
         }
+        // the segment's finisher: the workgroup that takes the last ticket (behind its waves' drained memory operations)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned int ticket = atomicAdd(A.done_counter, 1u);
+            s_last = (ticket == gridDim.x - 1);
+            if (s_last) __hip_atomic_store(A.done_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (s_last && threadIdx.x < LG_BLOCK) roll_finish(A, threadIdx.x, step0);
         LG_PROF_END(PF_EXTRAS, A.prof);
-        return;                    // extras["episode"] and the step counter: k_roll_finish, behind this launch
+        return;
     } else one_step(0);
     const int64_t step = step0;
     LG_PROF(PF_POST);
@@ -1914,22 +1946,6 @@ __global__ void __launch_bounds__(64) k_extras(const KArgs A) {        // behind
     const int64_t last = A.step >= 0 ? A.step : (A.B.step_counter ? A.B.step_counter[0] : 0);
     finish_extras(A, threadIdx.x, A.step, false, A.B.extras_accum, A.flush_parts > 0 ? level_parts_slot(A, last, A.flush_parts) : nullptr, A.flush_parts);
     if (A.accum_alt) finish_extras(A, threadIdx.x, A.step, false, A.accum_alt, nullptr, 0, false);
-}
-
-// ------------------------------------------------------------------ lg_rollout_policy: around the multi-step launch
-__global__ void __launch_bounds__(64) k_roll_finish(const KArgs A) {
-    // extras["episode"] (legged_robot.py:179-188): the sums of the LAST step of the launch in which any env was reset (the dictionary
-    // stays stale otherwise, quirk Q4); the device step counter moves to the last executed step.
-    const lg_params &P = A.P;
-    const int t = threadIdx.x, R = P.num_reward_slots, stride = LG_NUM_REWARD_TERMS + 2;
-    const int64_t step0 = A.step >= 0 ? A.step : (A.B.step_counter ? A.B.step_counter[0] + 1 : 0);
-    int last = -1;
-    for (int s = A.roll.steps - 1; s >= 0 && last < 0; s--) if (A.roll.extras[(size_t)s * stride + R] > 0.0f) last = s;
-    if (last >= 0 && t < R) A.B.episode_means[t] = A.roll.extras[(size_t)last * stride + t] / A.roll.extras[(size_t)last * stride + R] / P.max_episode_length_s;
-    __builtin_amdgcn_s_waitcnt(0);
-    if (t == 0 && A.B.step_counter) A.B.step_counter[0] = step0 + A.roll.steps - 1;
-    __syncthreads();
-    for (int i = t; i < A.roll.steps * stride; i += 64) A.roll.extras[i] = 0.0f;        // ready for the next segment (zeroed once at allocation)
 }
 
 // ------------------------------------------------------------------ sub-path kernels (parity tests drive these)
@@ -3192,7 +3208,7 @@ int lg_rollout_policy(lg_sim *s, lg_policy *p, const lg_rollout_buffers *r, uint
         if (cap != hipStreamCaptureStatusNone) return fail(-9, "first lg_rollout_policy call on a handle allocates its workspace: make one call outside stream capture");
         HIP_TRY(hipSetDevice(s->device));
         if (hipMalloc(&s->d_roll_extras, sizeof(float) * LG_MAX_ROLL_STEPS * stride) != hipSuccess) return fail(-10, "hipMalloc failed");
-        HIP_TRY(hipMemset(s->d_roll_extras, 0, sizeof(float) * LG_MAX_ROLL_STEPS * stride));      // k_roll_finish leaves it zeroed after every segment
+        HIP_TRY(hipMemset(s->d_roll_extras, 0, sizeof(float) * LG_MAX_ROLL_STEPS * stride));      // roll_finish leaves it zeroed after every segment
     }
     KArgs a; fill_args(s, a, common_step_counter); a.actions_in = nullptr; a.defer = 0;
     fill_policy_args(p, a.pol, r->obs, r->actions, r->mean, s->P.num_envs, seed, common_step_counter, s->B.step_counter, deterministic);
@@ -3203,7 +3219,6 @@ int lg_rollout_policy(lg_sim *s, lg_policy *p, const lg_rollout_buffers *r, uint
         hipLaunchKernelGGL((k_step<AnymalTraits, true, false, true, 4, true, true>), dim3(grid_for<AnymalTraits>(s->P.num_envs)), dim3(LG_STEP_WAVES * LG_BLOCK), 0, st, a);
     else
         hipLaunchKernelGGL((k_step<AnymalTraits, true, false, true, 4, false, true>), dim3(grid_for<AnymalTraits>(s->P.num_envs)), dim3(LG_STEP_WAVES * LG_BLOCK), 0, st, a);
-    hipLaunchKernelGGL(k_roll_finish, dim3(1), dim3(64), 0, st, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }

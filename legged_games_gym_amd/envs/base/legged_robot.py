@@ -237,8 +237,8 @@ class LeggedRobot(BaseTask):
         return storage
 
     def make_graphed_rollout(self, fused_actor, steps, warmup=1):
-        """``rollout_policy(fused_actor, steps)`` on a fixed storage captured into one HIP graph (the multi-step kernel, which starts from
-        the previous replay's ``obs[steps]`` and copies it to ``obs[0]``, and the extras finisher): returns ``(replay, storage)``."""
+        """``rollout_policy(fused_actor, steps)`` on a fixed storage captured into one HIP graph (ONE kernel node: the multi-step kernel starts from
+        the previous replay's ``obs[steps]``, copies it to ``obs[0]``, and its last workgroup publishes ``extras["episode"]``): returns ``(replay, storage)``."""
         if self.cfg.commands.curriculum:
             raise NotImplementedError("commands.curriculum needs eager steps (host-side rule between steps)")
         sim = self._sim
