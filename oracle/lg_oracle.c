@@ -10,12 +10,23 @@
  *      reference legged_gym/envs/base/legged_robot.py:80-230, 329-444, 831-969,
  *      envs/anymal_c/anymal.py:56-81, envs/cassie/cassie.py:43-46,
  *      utils/math.py:38-48 and of the [EXTERNAL] isaacgym.torch_utils helpers
- *      (quat_rotate_inverse, quat_apply, torch_rand_float) it calls.  Pinned by
- *      tests/golden (actuator net probe from the reference's own .pt weights,
- *      numpy transcriptions of the cited lines).
+ *      (quat_rotate_inverse, quat_apply, torch_rand_float) it calls.  PINNED by
+ *      tests/golden: G1 (actuator net: the reference's own weights through
+ *      ATen's aten::lstm), G4 (post-physics block) and G5 (the reset / RNG half:
+ *      post_physics_step as a whole, reset_idx, terrain / command curricula,
+ *      command resampling, pushes, observation noise) -- all outputs of the
+ *      reference's OWN method bodies, ast-extracted from /root/reference and
+ *      executed by tools/make_golden.py, the random draws answered from this
+ *      file's Philox stream by an independent numpy Philox4x32-10 (Random123
+ *      known answers): tests/test_oracle_torch_side.py, test_oracle_reset_half.py.
  *  (2) PHYSICS HALF -- the reference delegates gym.simulate() to PhysX
- *      (closed source, absent): PARITY UNPINNED against PhysX.  This file
- *      *defines* the rigid-body step the HIP kernels must reproduce:
+ *      (closed source, absent): PARITY UNPINNED against PhysX itself.  The
+ *      DYNAMICS of a sub-step are tied to the published equations of motion
+ *      by tests/test_equation_of_motion.py (independent float64 recursive
+ *      Newton-Euler on all four robots: residual <= 2e-5; single-joint
+ *      oscillation period vs 2 pi sqrt(I / Kp)); the CONTACT model is defined
+ *      here and validated by invariants (tests/test_oracle_physics.py).  This
+ *      file *defines* the rigid-body step the HIP kernels must reproduce:
  *      floating-base articulated-body algorithm in world-aligned coordinates,
  *      every body's spatial quantities about its own joint origin, implicit (backward-Euler) spring-damper contacts
  *      and joint limits folded into the articulated inertias, implicit regularised
