@@ -346,6 +346,35 @@ def test_missed_handover_is_a_sticky_error(skip, bit):
     assert d.sim.device_status(True) == 0 and torch.isfinite(d.buf["root_states"]).all()
 
 
+def test_rollout_policy_segment_length_limits():
+    """steps = 1 (first and last step at once) equals one lg_step_policy; steps outside [1, LG_MAX_ROLL_STEPS] and malformed storage are refused."""
+    from legged_games_gym_amd import capi
+    from legged_games_gym_amd.rl import ActorCritic, FusedActor
+    from legged_games_gym_amd.utils.helpers import class_to_dict
+    from legged_games_gym_amd.envs import task_registry
+    outs = []
+    for rolled in (False, True):
+        env, _ = _env("anymal_c_flat", 70)
+        _, train_cfg = task_registry.get_cfgs("anymal_c_flat")
+        torch.manual_seed(3)
+        ac = ActorCritic(env.num_obs, env.num_obs, env.num_actions, **class_to_dict(train_cfg.policy)).to("cuda")
+        actor = FusedActor(ac, "cuda:0", seed=5)
+        env.reset()
+        if rolled:
+            st = env.rollout_policy(actor, 1)
+            outs.append((st["obs"][1].clone(), st["actions"][0].clone(), st["rew"][0].clone()))
+            with pytest.raises(RuntimeError, match="steps must be in"):
+                env.rollout_policy(actor, capi.LG_MAX_ROLL_STEPS + 1)
+            bad = dict(st); bad["rew"] = st["rew"].double()
+            with pytest.raises(ValueError, match="rollout storage 'rew'"):
+                env._sim.rollout_policy(actor, bad, 5)
+        else:
+            (act, _), (obs, _, rew, _, _) = env.step_policy(actor)
+            outs.append((obs.clone(), act.clone(), rew.clone()))
+    for x, y in zip(*outs):
+        assert float((x - y).abs().max()) < 5e-5
+
+
 @pytest.mark.parametrize("self_collision", [True, False])
 def test_rollout_policy_equals_sequential_fused_steps(self_collision):
     """lg_rollout_policy (T fused policy steps in ONE launch, per-step outputs in [t]-indexed rollout storage) == T lg_step_policy
