@@ -165,7 +165,7 @@ def worker(a):
     # torch's CUDA generator creates its graph-safe state at the first capture in the process; done under inference_mode (the
     # rollout graphs below) those tensors could not be touched by the later training leg.  Prime them in normal mode, keep alive.
     rng_prime = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(rng_prime):
+    with torch.cuda.graph(rng_prime, capture_error_mode="thread_local"):
         torch.zeros(1, device=dev).add_(1.0)
 
     import contextlib

@@ -162,7 +162,7 @@ class LeggedRobot(BaseTask):
         graph = torch.cuda.CUDAGraph()
         sim.set_deferred_extras(_DEFER_EXTRAS)
         try:
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 for _ in range(steps_per_replay):                # several policy steps per hipGraphLaunch: no host in between
                     sim.step(policy_act(self.obs_buf), -1)
                 if _DEFER_EXTRAS:
@@ -195,7 +195,7 @@ class LeggedRobot(BaseTask):
         graph = torch.cuda.CUDAGraph()
         sim.set_deferred_extras(_DEFER_EXTRAS)
         try:
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 for _ in range(steps_per_replay):
                     sim.step_policy(fused_actor, self.obs_buf, -1)
                 if _DEFER_EXTRAS:
@@ -252,7 +252,7 @@ class LeggedRobot(BaseTask):
         sim.buf["step_counter"].fill_(self.common_step_counter)
         graph = torch.cuda.CUDAGraph()
         T = int(steps)
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             sim.rollout_policy(fused_actor, storage, -1, False, obs0=storage["obs"][T])     # continues from the previous replay's last observations
         self._rollout_graph = graph
         self.obs_buf = storage["obs"][T]

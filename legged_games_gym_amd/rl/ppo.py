@@ -184,7 +184,7 @@ class PPO:
             # with autograd enabled cannot touch them.  Prime them here, in normal mode.
             # (kept alive: the generator drops the tensors again when its last graph goes away)
             self._prime = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._prime):
+            with torch.cuda.graph(self._prime, capture_error_mode="thread_local"):
                 torch.zeros(1, device=device).add_(1.0)
             self._lr = torch.tensor(float(learning_rate), device=device)
             self.optimizer = optim.Adam(self.actor_critic.parameters(), lr=self._lr, capturable=True)
@@ -542,7 +542,7 @@ class PPO:
             self._gstream.wait_stream(cur)
             self._zero_grad()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=self._gstream):
+            with torch.cuda.graph(g, stream=self._gstream, capture_error_mode="thread_local"):
                 if self._graph_whole:
                     for _ in range(self.num_learning_epochs):
                         for i in range(self.num_mini_batches):
@@ -612,13 +612,13 @@ class PPO:
                 pre = []
                 for i in range(nmb):
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, stream=self._gstream):
+                    with torch.cuda.graph(g, stream=self._gstream, capture_error_mode="thread_local"):
                         self._ix = views[i]
                         self._zero_grad()
                         self._mb_step_fused("pre")
                     pre.append(g)
                 post = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(post, stream=self._gstream):
+                with torch.cuda.graph(post, stream=self._gstream, capture_error_mode="thread_local"):
                     self._mb_step_fused("post")
                 self._dp_graphs = (pre, post)
             except Exception as exc:                  # capture refused (e.g. the torch MLP path): stay eager, say so once

@@ -222,7 +222,7 @@ class OnPolicyRunner:
                 env.begin_graph_capture()
                 captured = True
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                     obs, cobs = self._rollout_steps(stats)
                     if hasattr(env, "capture_extras_flush"):
                         env.capture_extras_flush()          # extras["episode"] of the rollout's last step (its steps defer them)
