@@ -15,7 +15,11 @@ from legged_games_gym_amd.rl import ActorCritic, FusedActor
 from legged_games_gym_amd.utils.helpers import class_to_dict
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 args = get_args(["--task", "anymal_c_flat", "--num_envs", "4096", "--headless", "--sim_device", "cuda:0", "--rl_device", "cuda:0"])
-env, cfg = task_registry.make_env("anymal_c_flat", args)
+env_cfg, _ = task_registry.get_cfgs("anymal_c_flat")
+if os.environ.get("LG_NO_SC"):               # the same workload without self-collision (asset.self_collisions = 1)
+    env_cfg.asset.self_collisions = 1
+env, cfg = task_registry.make_env("anymal_c_flat", args, env_cfg=env_cfg)
+print("self-collision:", env.self_collision_modelled)
 env.set_fixed_commands(0.5, 0.0, 0.0)
 _, tcfg = task_registry.get_cfgs("anymal_c_flat")
 torch.manual_seed(1)
