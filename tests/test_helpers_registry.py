@@ -145,3 +145,22 @@ def test_no_task_is_flagged_experimental_and_custom_actuator_files_are_refused(t
     blob = tmp_path / "net.f32"
     np.arange(972, dtype="<f4").tofile(blob)
     assert packing.load_actuator_weights(str(blob))[5] == 5.0
+
+
+def test_committed_pmc_summary_has_what_bench_reads():
+    """bench.py takes `roofline.traffic` / `mfma_busy_pct` from profiles/r03_pmc_summary.json (tools/collect_r03.sh + pmc_summary_r03.py):
+    the three single-GPU BASELINE configs must be there with the keys it reads, at the env counts it runs them with."""
+    import json
+    import os
+    repo = os.path.dirname(os.path.dirname(os.path.realpath(__file__)))
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(repo, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    pm = json.load(open(bench.PMC_SUMMARY))["tasks"]
+    for task, envs in (("anymal_c_flat", 4096), ("anymal_c_rough", 4096), ("cassie", 8192)):
+        e = pm[task]
+        assert e["envs_per_gpu"] == envs
+        k = e["k_step"]
+        assert k["steps_per_launch"] >= 1 and k["traffic_bytes_per_launch"] > 1e6 and 0.0 <= k["mfma_busy_frac_of_busy_cycles"] < 1.0
+        assert k["algorithmic_bytes_per_policy_step"] == bench.BYTES_PER_ENV_STEP[task] * envs
+    assert pm["anymal_c_flat"]["k_step"]["steps_per_launch"] == 20 and "true, true>" in pm["anymal_c_flat"]["k_step"]["kernel"]     # the multi-step kernel
