@@ -275,7 +275,7 @@ def check_contact_forces_are_the_external_force(h, N, seed, min_exact):
         # this one sub-step.  So the force that acted is never MORE than the exported one, the gap is along the plane's normal and it is
         # bounded by the damper over one pass's velocity change.
         assert abs(miss[0]) < 2e-3 and abs(miss[1]) < 2e-3, (e, miss)
-        assert -0.25 < miss[2] < 0.0, (e, miss)
+        assert -0.5 < miss[2] < 0.0, (e, miss)
     assert loaded >= free.sum() // 2, loaded             # the robots did stand on something
     assert exact >= min_exact * free.sum(), (exact, int(free.sum()))
     return worst_exact
