@@ -345,23 +345,32 @@ __global__ void __launch_bounds__(256) k_gemm_wide_bf16x3(const GemmArgs G) {
     // outside the matrix (widths that are multiples of 4) -- one predicated 16-byte load per operand quad.  The general load4() with its
     // per-element tails costs ~25 executed instructions per quad even when no tail exists: with it a stage was ~700 instructions per
     // wave for 24 MFMAs and the kernels were instruction-issue bound.
-    const bool quads = (N.M & 3) == 0 && (N.N & 3) == 0 && !(MODE == GEMM_DW && G.gather_b_k) && !(MODE == GEMM_FWD && G.gather_a_rows);
-    auto ld4 = [&](const float *p, bool ok) {
-        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok) { const f32x4u v = *reinterpret_cast<const f32x4u *>(p); r = make_float4(v.x, v.y, v.z, v.w); }
-        return r;
+    //
+    // The fast loads are UNCONDITIONAL and land in the registers the next store_stage() reads: a quad outside the matrix is fetched from a
+    // clamped, valid address instead of being predicated off (its values only reach output rows / columns the epilogue never stores, and
+    // the bias column sum of rows it never stores).  With a predicated load (`r = 0; if (ok) r = load`) or a fast / general branch inside
+    // the loop the compiler loads into temporaries and merges them with v_mov behind an `s_waitcnt vmcnt(0)` placed BEFORE the MFMA block:
+    // every stage then waited for its own prefetch and the kernels ran at memory time PLUS matrix time (52.9 us for dW of layer 1 =
+    // 37.3 us without its MFMAs + 15.4 us of MFMAs) instead of the larger of the two.  Hence two copies of the main loop, chosen once.
+    // dW of layer 0: the input rows are 235 / 169 wide but stored zero-padded to a multiple of 4 (k_wide_prep), so the last quad is
+    // readable too (its extra output column is never stored).
+    const int Npad = (MODE == GEMM_DW && ((N.N + 3) & ~3) <= N.ldb) ? ((N.N + 3) & ~3) : N.N;
+    const bool quads = (N.M & 3) == 0 && (Npad & 3) == 0 && !(MODE == GEMM_DW && G.gather_b_k) && !(MODE == GEMM_FWD && G.gather_a_rows);
+    const bool fast = quads && k_end > k_begin && ((k_end - k_begin) % LG_BK) == 0;
+    const float *pa_f = pa, *pb_f = pb;                   // clamped bases of the fast loads
+    if (!A_KC && na != 4) pa_f = N.A;
+    if (!B_KC && n0 + 4 * (t & 31) + 4 > Npad) pb_f = N.B;
+    auto ldq = [&](const float *p) { const f32x4u v = *reinterpret_cast<const f32x4u *>(p); return make_float4(v.x, v.y, v.z, v.w); };
+    auto load_fast = [&](int kb) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            if (A_KC) ra[c] = ldq(pa_f + kb + 16 * (t & 1) + 4 * c);
+            else ra[c] = ldq(pa_f + (size_t)(kb + 4 * (t >> 5) + c) * N.lda);
+            if (B_KC) rb[c] = ldq(pb_f + kb + 16 * (t & 1) + 4 * c);
+            else rb[c] = ldq(pb_f + (size_t)(kb + 4 * (t >> 5) + c) * N.ldb);
+        }
     };
     auto load_stage = [&](int kb) {
-        if (quads && kb + LG_BK <= k_end) {
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                if (A_KC) ra[c] = ld4(pa + kb + 16 * (t & 1) + 4 * c, na != 0);
-                else ra[c] = ld4(pa + (size_t)(kb + 4 * (t >> 5) + c) * N.lda, na == 4);
-                if (B_KC) rb[c] = ld4(pb + kb + 16 * (t & 1) + 4 * c, nb != 0);
-                else rb[c] = ld4(pb + (size_t)(kb + 4 * (t >> 5) + c) * N.ldb, nb == 4);
-            }
-            return;
-        }
 #pragma unroll
         for (int c = 0; c < 4; c++) {
             if (A_KC) { const int k = kb + 16 * (t & 1) + 4 * c; ra[c] = load4(pa + k, na ? k_end - k : 0); }
@@ -418,11 +427,7 @@ __global__ void __launch_bounds__(256) k_gemm_wide_bf16x3(const GemmArgs G) {
             for (int c = 0; c < 16; c++) acc[i][j][c] = 0.0f;
     const int n_stage = (k_end - k_begin + LG_BK - 1) / LG_BK;
     const int li = lane & 31, lh = lane >> 5;
-    if (n_stage > 0) load_stage(k_begin);
-    for (int s = 0; s < n_stage; s++) {
-        store_stage();                                            // registers of stage s -> LDS (the previous stage's readers passed the barrier below)
-        __syncthreads();
-        if (s + 1 < n_stage) load_stage(k_begin + (s + 1) * LG_BK);      // in flight during this stage's MFMAs
+    auto mfma_stage = [&]() {
 #pragma unroll
         for (int ks = 0; ks < LG_BK; ks += 16) {
             bf16x8g ah[2], al[2], bh[2], bl[2];
@@ -452,7 +457,26 @@ __global__ void __launch_bounds__(256) k_gemm_wide_bf16x3(const GemmArgs G) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
         }
-        __syncthreads();                                          // all fragment reads of this stage done before the next store
+    };
+    if (fast) {
+        load_fast(k_begin);
+        for (int s = 0; s < n_stage; s++) {
+            store_stage();                                        // registers of stage s -> LDS (the previous stage's readers passed the barrier below)
+            __syncthreads();
+            load_fast(k_begin + min(s + 1, n_stage - 1) * LG_BK); // in flight during this stage's MFMAs (the last stage is fetched twice: no branch)
+            __builtin_amdgcn_sched_barrier(0);                    // ... all of them: the scheduler otherwise sinks the loads behind the MFMAs
+            mfma_stage();
+            __syncthreads();                                      // all fragment reads of this stage done before the next store
+        }
+    } else {
+        if (n_stage > 0) load_stage(k_begin);
+        for (int s = 0; s < n_stage; s++) {
+            store_stage();
+            __syncthreads();
+            if (s + 1 < n_stage) load_stage(k_begin + (s + 1) * LG_BK);
+            mfma_stage();
+            __syncthreads();
+        }
     }
     float *C = N.C + (MODE == GEMM_DW ? (size_t)split * N.M * N.ldc : 0);
     if (MODE == GEMM_DW && tile_n == 0) {                         // fold the 8 k-groups (t >> 5) of each feature through LDS, fixed order
@@ -492,17 +516,23 @@ __global__ void __launch_bounds__(256) k_wide_prep(const WidePrepArgs P) {
 // element (lane q sums the splits q, q + group, ... in order, then a fixed xor butterfly): 1 for the big layers (coalesced, bandwidth-bound),
 // 8 for the narrow output layer, whose 256 chunks x 1.6 k elements are pure load latency (12.9 us with one lane per element and 8 loads
 // in flight, 8.0 us with 16).  Either way the order of the additions is fixed: the gradients are bit-reproducible.
-struct WideReduceArgs { const float *part[2]; float *gw[2], *gb[2]; int N[2], K[2], ld[2], splits[2]; int group; };     // ld: row stride of a partial (K + 1 rounded up to 4)
+#define LG_REDUCE_JOBS 8               // 4 layers x 2 nets: ONE launch at the end of the backward pass (four launches of 5-13 us, one of them pure
+                                       // latency, were 30 us per mini-batch)
+struct WideReduceJob { const float *part; float *gw, *gb; int N, K, ld, splits, group; };     // ld: row stride of a partial (K + 1 rounded up to 4)
+struct WideReduceArgs { WideReduceJob job[LG_REDUCE_JOBS]; };
 __global__ void __launch_bounds__(256) k_wide_reduce(const WideReduceArgs R) {
-    const int z = blockIdx.y, N = R.N[z], K = R.K[z], ld = R.ld[z], G = R.group;
+    const WideReduceJob &J = R.job[blockIdx.y];
+    const int N = J.N, K = J.K, ld = J.ld, G = J.group;
+    if (G <= 0) return;
     const int t = blockIdx.x * 256 + threadIdx.x, i = t / G, q = t % G;
+    if ((blockIdx.x * 256) / G >= N * ld) return;   // whole workgroup beyond this job (the grid is sized for the largest)
     const bool in = i < N * ld;                     // (whole groups are in or out: 256 is a multiple of G)
     const int n = in ? i / ld : 0, k = in ? i % ld : 0;
     float s = 0.0f;
     if (in && k <= K) {
         const size_t stride = (size_t)N * ld;
-        const float *src = R.part[z] + i;
-        const int S = R.splits[z];
+        const float *src = J.part + i;
+        const int S = J.splits;
         int p = q;
         for (; p + 15 * G < S; p += 16 * G) {       // 16 independent loads in flight
             float v[16];
@@ -515,8 +545,8 @@ __global__ void __launch_bounds__(256) k_wide_reduce(const WideReduceArgs R) {
     }
     for (int o = 1; o < G; o <<= 1) s += __shfl_xor(s, o);
     if (!in || k > K || q != 0) return;
-    if (k < K) R.gw[z][(size_t)n * K + k] = s;
-    else R.gb[z][n] = s;
+    if (k < K) J.gw[(size_t)n * K + k] = s;
+    else J.gb[n] = s;
 }
 
 

@@ -2451,13 +2451,15 @@ int lg_ppo_minibatch(const lg_mlp_net *nets, const int64_t *rows, int32_t mb, co
 }
 
 // ---- learner kernels for the wide MLPs (lg_gemm.h): per layer a tiled f32-MFMA GEMM with the element-wise work in its epilogue
-struct WideLayout { size_t x[4], g[4], part, x0p, w0p, wpk[4], bpk[4], total; int splits[4]; int kchunk[4]; int k0p; int ks[4], ot[4]; bool chain; int out_chunks; bool out_narrow; };      // float offsets into one net's workspace slice
+struct WideLayout { size_t x[4], g[4], part[4], x0p, w0p, wpk[4], bpk[4], total; int splits[4]; int kchunk[4]; int k0p; int ks[4], ot[4]; bool chain; int out_chunks; bool out_narrow; };      // float offsets into one net's workspace slice
 static void wide_layout(const lg_mlp_net &n, int mb, WideLayout &L) {
     size_t o = 0;
     for (int l = 1; l <= 3; l++) { L.x[l] = o; o += (size_t)mb * n.dims[l]; }
     for (int l = 1; l <= 3; l++) { L.g[l] = o; o += (size_t)mb * n.dims[l]; }
-    size_t pmax = 0;
-    for (int l = 0; l < 4; l++) {
+    L.out_narrow = n.dims[3] == 128 && n.dims[4] <= LG_OUT_MAXN;      // k_wide_out_bwd: dX + dW of the output layer in one pass
+    L.out_chunks = mb >= 2048 ? 256 : (mb + 7) / 8;
+    o = (o + 3) & ~(size_t)3;
+    for (int l = 0; l < 4; l++) {                                     // one partial buffer per layer: all four are summed by ONE k_wide_reduce launch
         const int tiles = ((n.dims[l + 1] + LG_GT - 1) / LG_GT) * ((n.dims[l] + LG_GT - 1) / LG_GT);
         int sp = (384 + tiles - 1) / tiles;                                   // enough workgroups for the chip: tiles x splits >= ~1.5 x CUs
         if (sp > LG_WIDE_MAX_SPLITS) sp = LG_WIDE_MAX_SPLITS;
@@ -2466,14 +2468,10 @@ static void wide_layout(const lg_mlp_net &n, int mb, WideLayout &L) {
         if (chunk < LG_BK) chunk = LG_BK;
         sp = (mb + chunk - 1) / chunk;
         L.splits[l] = sp; L.kchunk[l] = chunk;
-        const size_t p = (size_t)sp * n.dims[l + 1] * ((n.dims[l] + 1 + 3) & ~3);
-        if (p > pmax) pmax = p;
+        size_t p = (size_t)sp * n.dims[l + 1] * ((n.dims[l] + 1 + 3) & ~3);
+        if (l == 3 && L.out_narrow) { const size_t q = (size_t)L.out_chunks * n.dims[4] * ((n.dims[3] + 1 + 3) & ~3); if (q > p) p = q; }
+        L.part[l] = o; o += (p + 3) & ~(size_t)3;
     }
-    L.out_narrow = n.dims[3] == 128 && n.dims[4] <= LG_OUT_MAXN;      // k_wide_out_bwd: dX + dW of the output layer in one pass
-    L.out_chunks = mb >= 2048 ? 256 : (mb + 7) / 8;
-    if (L.out_narrow) { const size_t p = (size_t)L.out_chunks * n.dims[4] * ((n.dims[3] + 1 + 3) & ~3); if (p > pmax) pmax = p; }
-    L.part = o; o += pmax;
-    o = (o + 3) & ~(size_t)3;
     L.k0p = (n.dims[0] + 3) & ~3;                     // aligned, gather-free copies of the layer-0 operands (k_wide_prep)
     L.x0p = o; o += (size_t)mb * L.k0p;
     L.w0p = o; o += (size_t)n.dims[1] * L.k0p;
@@ -2625,35 +2623,36 @@ int lg_mlp_wide_backward(const lg_mlp_net *nets, int32_t n_nets, const int64_t *
     hipStream_t st = (hipStream_t)stream;
     bool narrow = true;
     for (int n = 0; n < n_nets; n++) { WideLayout L; wide_layout(nets[n], mb, L); narrow = narrow && L.out_narrow; }
+    lg::WideReduceArgs red; memset(&red, 0, sizeof red);            // the partials of all layers, summed by one launch behind the last GEMM
+    int red_max = 0;
+    auto add_job = [&](int l, int n, const float *part, int N_, int K_, int ld, int splits, int group) {
+        lg::WideReduceJob &j = red.job[2 * l + n];
+        j.part = part; j.gw = nets[n].grad_weights[l]; j.gb = nets[n].grad_biases[l]; j.N = N_; j.K = K_; j.ld = ld; j.splits = splits; j.group = group;
+        if (N_ * ld * group > red_max) red_max = N_ * ld * group;
+    };
     for (int l = 3; l >= 0; l--) {
         if (l == 3 && narrow) {                        // the <= 16-wide output layer: G_3, dW_3, db_3 from one read of A_3 (lg_gemm.h: k_wide_out_bwd)
             lg::OutBwdArgs o; memset(&o, 0, sizeof o);
-            lg::WideReduceArgs r; memset(&r, 0, sizeof r);
             o.mb = mb;
-            int chunks = 0, rmax = 0;
+            int chunks = 0;
             float *ws = workspace;
             for (int n = 0; n < n_nets; n++) {
                 WideLayout L; wide_layout(nets[n], mb, L);
                 const int32_t *d = nets[n].dims;
                 lg::OutBwdNet &q = o.net[n];
-                q.dz = nets[n].grad_output; q.w = nets[n].weights[3]; q.act = ws + L.x[3]; q.g = ws + L.g[3]; q.part = ws + L.part;
+                q.dz = nets[n].grad_output; q.w = nets[n].weights[3]; q.act = ws + L.x[3]; q.g = ws + L.g[3]; q.part = ws + L.part[3];
                 q.N = d[4]; q.K = d[3]; q.ld = (d[3] + 1 + 3) & ~3; q.chunks = L.out_chunks; q.rows_per_chunk = (mb + L.out_chunks - 1) / L.out_chunks;
                 if (q.chunks > chunks) chunks = q.chunks;
-                r.part[n] = q.part; r.gw[n] = nets[n].grad_weights[3]; r.gb[n] = nets[n].grad_biases[3];
-                r.N[n] = d[4]; r.K[n] = d[3]; r.ld[n] = q.ld; r.splits[n] = q.chunks;
-                if (d[4] * q.ld > rmax) rmax = d[4] * q.ld;
+                add_job(3, n, q.part, d[4], d[3], q.ld, q.chunks, 8);
                 ws += L.total;
             }
             hipLaunchKernelGGL((lg::k_wide_out_bwd<LG_OUT_MAXN>), dim3(chunks, n_nets), dim3(256), 0, st, o);
-            r.group = 8;
-            hipLaunchKernelGGL(lg::k_wide_reduce, dim3((rmax * r.group + 255) / 256, n_nets), dim3(256), 0, st, r);
             continue;
         }
         // dW_l, db_l (split over the mini-batch rows) ...
         lg::GemmArgs a; memset(&a, 0, sizeof a);
-        lg::WideReduceArgs r; memset(&r, 0, sizeof r);
         a.rows = nullptr; a.gather_b_k = 0; a.mb = mb;          // layer 0 reads the gathered copy the forward pass left in the workspace
-        int gx = 0, gy = 0, rmax = 0;
+        int gx = 0, gy = 0;
         float *ws = workspace;
         for (int n = 0; n < n_nets; n++) {
             WideLayout L; wide_layout(nets[n], mb, L);
@@ -2661,19 +2660,15 @@ int lg_mlp_wide_backward(const lg_mlp_net *nets, int32_t n_nets, const int64_t *
             const int32_t *d = nets[n].dims;
             g.A = l == 3 ? nets[n].grad_output : ws + L.g[l + 1]; g.lda = d[l + 1];
             g.B = l == 0 ? wide_x0p(nets, n_nets, mb, workspace, n) : ws + L.x[l]; g.ldb = l == 0 ? L.k0p : d[l];
-            g.C = ws + L.part; g.ldc = (d[l] + 1 + 3) & ~3;
+            g.C = ws + L.part[l]; g.ldc = (d[l] + 1 + 3) & ~3;
             g.M = d[l + 1]; g.N = d[l]; g.K = mb; g.splits = L.splits[l]; g.k_chunk = L.kchunk[l];
             g.tiles_m = (g.M + LG_GT - 1) / LG_GT; g.tiles_n = (d[l] + LG_GT - 1) / LG_GT;
             if (g.tiles_m > gx) gx = g.tiles_m;
             if (g.tiles_n * g.splits > gy) gy = g.tiles_n * g.splits;
-            r.part[n] = ws + L.part; r.gw[n] = nets[n].grad_weights[l]; r.gb[n] = nets[n].grad_biases[l];
-            r.N[n] = d[l + 1]; r.K[n] = d[l]; r.ld[n] = (d[l] + 1 + 3) & ~3; r.splits[n] = L.splits[l];
-            if (d[l + 1] * r.ld[n] > rmax) rmax = d[l + 1] * r.ld[n];
+            add_job(l, n, ws + L.part[l], d[l + 1], d[l], (d[l] + 1 + 3) & ~3, L.splits[l], 1);
             ws += L.total;
         }
         LAUNCH_WIDE(lg::GEMM_DW, dim3(gx, gy, n_nets), a)
-        r.group = 1;
-        hipLaunchKernelGGL(lg::k_wide_reduce, dim3((rmax + 255) / 256, n_nets), dim3(256), 0, st, r);
         if (l == 0) break;
         // ... and G_l = (G_{l+1} W_l) * elu'(X_l)
         lg::GemmArgs b; memset(&b, 0, sizeof b);
@@ -2694,6 +2689,7 @@ int lg_mlp_wide_backward(const lg_mlp_net *nets, int32_t n_nets, const int64_t *
         }
         LAUNCH_WIDE(lg::GEMM_DX, dim3(gx, gy, n_nets), b)
     }
+    hipLaunchKernelGGL(lg::k_wide_reduce, dim3((red_max + 255) / 256, LG_REDUCE_JOBS), dim3(256), 0, st, red);
     HIP_TRY(hipGetLastError());
     return 0;
 }
