@@ -314,8 +314,10 @@ struct ChainArgs { ChainNet net[2]; int mb; };
 // (1.16 MB per workgroup whatever the rows) is paid once per 64 rows.  A 64-row x1 (512 wide, hi + lo) alone would be 128 KB of LDS, so
 // layer 0 runs in two phases of 8 output tiles and layer 1 accumulates over the 16 k-steps each phase leaves in LDS: two 64 KB
 // buffers hold x0 | x2 and half of x1 | x3.
+#define LG_CHAIN_INFLIGHT 32           // 1-KB weight loads a wave of the chain keeps in flight: 17 ring slots = a whole 16-k-step segment requested by prime().
+                                       // (With the tile's biases held between the MFMAs and the epilogue the kernel spills 8 registers; 15 slots: no spill, 130 vs 122 us.)
 template <int KS, int KTOT> struct WideStream2 {                  // one output tile, k-steps k0 .. k0+KS-1 of a layer with KTOT k-steps, two row halves
-    static constexpr int PF = (LG_PW_INFLIGHT / 2 + 1) < KS + 1 ? (LG_PW_INFLIGHT / 2 + 1) : KS + 1;     // one ring live at a time (two half-depth rings, the next segment
+    static constexpr int PF = (LG_CHAIN_INFLIGHT / 2 + 1) < KS + 1 ? (LG_CHAIN_INFLIGHT / 2 + 1) : KS + 1;     // one ring live at a time (two half-depth rings, the next segment
                                                                                                          // requested early, measured slower: 145 vs 130 us)
     bf16x8g wh[PF], wl[PF];
     LG_DEV void fetch(const bf16x8g *__restrict__ w, int tile, int k0, int rot, int lane, int s) {
@@ -336,21 +338,33 @@ template <int KS, int KTOT> struct WideStream2 {                  // one output 
         for (int s = 0; s < KS; s++) {
             if (s + PF - 1 < KS) fetch(w, tile, k0, rot, lane, s + PF - 1);
             int sr = s + rot; sr = sr >= KS ? sr - KS : sr;
-#pragma unroll
-            for (int hf = 0; hf < 2; hf++) {
-                const bf16x8g bh = xin[sr][hf][0][lane], bl = xin[sr][hf][1][lane];
-                acc[hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[s % PF], bh, acc[hf], 0, 0, 0);
-                acc[hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[s % PF], bl, acc[hf], 0, 0, 0);
-                acc[hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[s % PF], bh, acc[hf], 0, 0, 0);
-            }
+            // (the two row halves interleaved or one after the other: the same time)
+            const bf16x8g bh0 = xin[sr][0][0][lane], bl0 = xin[sr][0][1][lane], bh1 = xin[sr][1][0][lane], bl1 = xin[sr][1][1][lane];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[s % PF], bh0, acc[0], 0, 0, 0);     // small terms first
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[s % PF], bh1, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[s % PF], bl0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[s % PF], bl1, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[s % PF], bh0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[s % PF], bh1, acc[1], 0, 0, 0);
         }
     }
 };
 // bias + ELU of one finished tile (both row halves): f32 activations to global (column block `tile_g`), split -> LDS k-steps 2 tile_l, 2 tile_l + 1
-LG_DEV void chain_epilogue2(const f32x16p (&acc)[2], const float *__restrict__ b, bf16x8g (*xout)[2][2][64], int tile_g, int tile_l, int lane,
+// (the lane's 16 biases of the tile are fetched by chain_bias() BEFORE the next layer's weight ring is primed: loads return in order,
+// and behind the ring's 32 KB per wave the epilogue started with ~1 k cycles of waiting)
+struct ChainBias { float4 q[4]; };
+LG_DEV ChainBias chain_bias(const float *__restrict__ b, int tile_g, int lane) {
+    const float4 *bo = reinterpret_cast<const float4 *>(b + 32 * tile_g + 4 * (lane >> 5));
+    ChainBias r;
+#pragma unroll
+    for (int c = 0; c < 4; c++) r.q[c] = bo[2 * c];          // floats 8 c .. 8 c + 3 of this lane's half
+    return r;
+}
+LG_DEV void chain_epilogue2(const f32x16p (&acc)[2], const ChainBias &B, bf16x8g (*xout)[2][2][64], int tile_g, int tile_l, int lane,
                             float *__restrict__ act0, float *__restrict__ act1 /* the lane's rows of the two halves, or null */) {
     const int h = lane >> 5;
-    const float *bo = b + 32 * tile_g + 4 * h;
+    const float bo[16] = {B.q[0].x, B.q[0].y, B.q[0].z, B.q[0].w, B.q[1].x, B.q[1].y, B.q[1].z, B.q[1].w,
+                          B.q[2].x, B.q[2].y, B.q[2].z, B.q[2].w, B.q[3].x, B.q[3].y, B.q[3].z, B.q[3].w};
 #pragma unroll
     for (int hf = 0; hf < 2; hf++) {
         float *act_row = hf ? act1 : act0;
@@ -358,7 +372,7 @@ LG_DEV void chain_epilogue2(const f32x16p (&acc)[2], const float *__restrict__ b
         for (int jj = 0; jj < 2; jj++) {
             float v[8];
 #pragma unroll
-            for (int i = 0; i < 8; i++) v[i] = elu1(acc[hf][8 * jj + i] + bo[8 * (2 * jj + (i >> 2)) + (i & 3)]);
+            for (int i = 0; i < 8; i++) v[i] = elu1(acc[hf][8 * jj + i] + bo[4 * (2 * jj + (i >> 2)) + (i & 3)]);
             if (act_row) {
                 float *dst = act_row + 32 * tile_g + 16 * jj + 4 * h;
                 *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
@@ -371,6 +385,12 @@ LG_DEV void chain_epilogue2(const f32x16p (&acc)[2], const float *__restrict__ b
     }
 }
 
+#ifdef LG_CHAIN_PROF
+__device__ unsigned long long g_chain_prof[2048 * 16];
+#define CHAIN_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.y == 0) g_chain_prof[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CHAIN_STAMP(i) do { } while (0)
+#endif
 template <int K0S>                                               // hidden widths 512-256-128 (16 / 8 / 4 tiles), 8 waves
 __global__ void __launch_bounds__(64 * LG_PW_WAVES) k_mlp_chain_fwd64(const ChainArgs C) {
     static_assert(LG_PW_WAVES == 8 && K0S <= 16, "one layer-1 tile per wave; x0 fits the 16 k-step buffer");
@@ -379,53 +399,87 @@ __global__ void __launch_bounds__(64 * LG_PW_WAVES) k_mlp_chain_fwd64(const Chai
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5;
     const int wv = (wave + blockIdx.x) & 7;
     const int r0 = (blockIdx.x * 5) % K0S, r1 = (blockIdx.x * 5) & 15, r2 = (blockIdx.x * 3) & 15;
-    int row[2]; bool live[2]; float *arow[3][2];
+    int row[2]; bool live[2];
 #pragma unroll
     for (int hf = 0; hf < 2; hf++) {
         row[hf] = blockIdx.x * 64 + 32 * hf + (lane & 31);
         live[hf] = row[hf] < C.mb;
         if (!live[hf]) row[hf] = C.mb - 1;
+    }
+    auto arow = [&](int l, int hf) -> float * { return live[hf] ? N.act[l] + (size_t)row[hf] * N.lda[l] : nullptr; };     // (formed at the epilogue: six
+                                                                                                                           // pointers held across the MFMA phases cost 12 registers)
+    CHAIN_STAMP(0);
+    // x0 of both halves -> bufA.  All of a wave's input loads (16-byte vectors: the rows are zero-padded to a multiple of 4 floats by
+    // k_wide_prep) are requested BEFORE the weight ring is primed -- loads return in order, and behind 32 KB of weights per wave the
+    // inputs arrived last: the first barrier was 16 k cycles into the 82 k of a workgroup (now 11 k; one coalesced request per row
+    // instead of these 32-byte gathers: 9.5 k, but 9 spilled registers and no faster overall).
+    constexpr int NX = (2 * K0S + LG_PW_WAVES - 1) / LG_PW_WAVES;
+    float4 xv[NX][2];
 #pragma unroll
-        for (int l = 0; l < 3; l++) arow[l][hf] = live[hf] ? N.act[l] + (size_t)row[hf] * N.lda[l] : nullptr;
+    for (int j = 0; j < NX; j++) {
+        const int s = min(wave + LG_PW_WAVES * j, 2 * K0S - 1), ks = s >> 1, hf = s & 1, k0 = 16 * ks + 8 * h;
+        const float *o = N.x + (size_t)row[hf] * N.ldx + k0;
+        xv[j][0] = *reinterpret_cast<const float4 *>(k0 + 4 <= N.ldx ? o : N.x);          // clamped, zeroed below: no predicated load
+        xv[j][1] = *reinterpret_cast<const float4 *>(k0 + 8 <= N.ldx ? o + 4 : N.x);
     }
     WideStream2<K0S, K0S> s0;
     s0.prime(N.wb[0], wv, 0, r0, lane);
-    for (int s = wave; s < 2 * K0S; s += LG_PW_WAVES) {           // x0 of both halves -> bufA
-        const int ks = s >> 1, hf = s & 1;
-        const float *o = N.x + (size_t)row[hf] * N.ldx;
-        float v[8];
 #pragma unroll
-        for (int i = 0; i < 8; i++) { const int k = 16 * ks + 8 * h + i; v[i] = k < N.num_in ? o[k] : 0.0f; }
+    for (int j = 0; j < NX; j++) {
+        const int s = wave + LG_PW_WAVES * j, ks = s >> 1, hf = s & 1, k0 = 16 * ks + 8 * h;
+        if (s >= 2 * K0S) break;
+        const bool in0 = k0 + 4 <= N.ldx, in1 = k0 + 8 <= N.ldx;
+        const float v[8] = {in0 ? xv[j][0].x : 0.f, in0 ? xv[j][0].y : 0.f, in0 ? xv[j][0].z : 0.f, in0 ? xv[j][0].w : 0.f,
+                            in1 ? xv[j][1].x : 0.f, in1 ? xv[j][1].y : 0.f, in1 ? xv[j][1].z : 0.f, in1 ? xv[j][1].w : 0.f};
         bf16x8g hi, lo;
         split8(v, hi, lo);
         bufA[ks][hf][0][lane] = hi; bufA[ks][hf][1][lane] = lo;
     }
     __syncthreads();
+    CHAIN_STAMP(1);
     f32x16p a0[2], a1[2];
     WideStream2<16, 32> s1;
 #pragma unroll                                                     // unrolled: only one weight ring is live at a time (a loop would carry both: 270 spills)
     for (int ph = 0; ph < 2; ph++) {
         s0.run(N.wb[0], bufA, 8 * ph + wv, 0, r0, lane, a0, true);                      // layer-0 tile 8 ph + wv
+        CHAIN_STAMP(2 + 4 * ph);
+        const ChainBias b0 = chain_bias(N.bb[0], 8 * ph + wv, lane);
+        __builtin_amdgcn_sched_barrier(0);
         s1.prime(N.wb[1], wv, 16 * ph, r1, lane);                                       // layer-1 tile wv, this phase's 16 k-steps
         __builtin_amdgcn_sched_barrier(0);
-        chain_epilogue2(a0, N.bb[0], bufB, 8 * ph + wv, wv, lane, arow[0][0], arow[0][1]);
+        chain_epilogue2(a0, b0, bufB, 8 * ph + wv, wv, lane, arow(0, 0), arow(0, 1));
+        CHAIN_STAMP(3 + 4 * ph);
         __syncthreads();
+        CHAIN_STAMP(4 + 4 * ph);
         s1.run(N.wb[1], bufB, wv, 16 * ph, r1, lane, a1, ph == 0);
         if (ph == 0) s0.prime(N.wb[0], 8 + wv, 0, r0, lane);
         __syncthreads();                                                                // bufB free again
+        CHAIN_STAMP(5 + 4 * ph);
     }
     WideStream2<16, 16> s2;
+    const ChainBias b1 = chain_bias(N.bb[1], wv, lane);
+    __builtin_amdgcn_sched_barrier(0);
     if (wv < 4) s2.prime(N.wb[2], wv, 0, r2, lane);
     __builtin_amdgcn_sched_barrier(0);
-    chain_epilogue2(a1, N.bb[1], bufA, wv, wv, lane, arow[1][0], arow[1][1]);           // x2 over x0 (every wave is past layer 0)
+    chain_epilogue2(a1, b1, bufA, wv, wv, lane, arow(1, 0), arow(1, 1));           // x2 over x0 (every wave is past layer 0)
     __syncthreads();
+    CHAIN_STAMP(10);
     f32x16p a2[2];
     WideStream2<8, 8> s3;
     if (wv < 4) s2.run(N.wb[2], bufA, wv, 0, r2, lane, a2, true);
+    const ChainBias b2 = chain_bias(N.bb[2], wv & 3, lane);
+    float by[4];                                                   // output biases of this lane's action groups (wave 0)
+#pragma unroll
+    for (int r = 0; r < 4; r++) by[r] = N.bb[3][4 * h + r];
+    float by2[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) by2[r] = N.bb[3][8 + 4 * h + r];
+    __builtin_amdgcn_sched_barrier(0);
     if (wave == 0) s3.prime(N.wb[3], 0, 0, 0, lane);
     __builtin_amdgcn_sched_barrier(0);
-    if (wv < 4) chain_epilogue2(a2, N.bb[2], bufB, wv, wv, lane, arow[2][0], arow[2][1]);
+    if (wv < 4) chain_epilogue2(a2, b2, bufB, wv, wv, lane, arow(2, 0), arow(2, 1));
     __syncthreads();
+    CHAIN_STAMP(11);
     if (wave != 0) return;
     f32x16p y[2];
     s3.run(N.wb[3], bufB, 0, 0, 0, lane, y, true);
@@ -437,9 +491,10 @@ __global__ void __launch_bounds__(64 * LG_PW_WAVES) k_mlp_chain_fwd64(const Chai
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int a = 8 * ii + 4 * h + r;
-                if (a < N.out_dim) N.out[(size_t)row[hf] * N.out_dim + a] = y[hf][4 * ii + r] + N.bb[3][a];
+                if (a < N.out_dim) N.out[(size_t)row[hf] * N.out_dim + a] = y[hf][4 * ii + r] + (ii ? by2[r] : by[r]);
             }
     }
+    CHAIN_STAMP(12);
 }
 
 // torch Linear [out, in] f32 -> the operand stream above; `first` selects the natural k order of layer 0

@@ -1,6 +1,6 @@
 // Stand-alone timing + spot check of the wide learner's GEMMs (csrc/lg_gemm.h) on the shapes of one PPO mini-batch of the rough tasks
 // (24 576 rows, 235-512-256-128 nets, actor + critic per launch).  Compiles in seconds (the full library takes minutes), so kernel
-// experiments are tried here first:  hipcc --offload-arch=gfx950 -O3 -std=c++17 -o gemm_probe gemm_probe.hip && ./gemm_probe
+// experiments are tried here first (build with the flags in chain_probe.hip)
 #include "../../legged_games_gym_amd/csrc/lg_gemm.h"
 #include <cstdio>
 #include <cstring>
