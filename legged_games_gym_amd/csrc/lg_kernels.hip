@@ -596,10 +596,14 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, int lane_k, float 
     HfFetch fb, fl[NPT];               // ground samples of all collision points: fetched here, evaluated after the loop
     V3 sgc[T::NGRP];          // self-collision: bounding-sphere centre of each point group (midpoint of its two anchor points)
     {
-        float mass_scale = base_mass / A.base.mass, Il[6];
+        // 6-joint chains (Cassie) run out of registers: values that do not change over the sub-steps are re-formed here instead of being
+        // hoisted out of the decimation loop and held (or spilled) across it -- the empty asm hides the invariance from LICM.
+        float bm = base_mass;
+        if (L > 3) asm volatile("" : "+v"(bm));
+        float mass_scale = bm / A.base.mass, Il[6];
 #pragma unroll
         for (int i = 0; i < 6; i++) Il[i] = A.base.inertia[i] * mass_scale;
-        body_terms(grav, base_mass, v3(A.base.com[0], A.base.com[1], A.base.com[2]), Il, R0, w0, v0, I0b, p0b);
+        body_terms(grav, bm, v3(A.base.com[0], A.base.com[1], A.base.com[2]), Il, R0, w0, v0, I0b, p0b);
         // base collision points are split over the env's lanes (lane i owns point i); their inertia / bias contribution
         // joins the lane's limb contribution before the butterfly, their force is butterfly-summed afterwards
         static_assert(K <= LG_MAX_BASE_POINTS, "one base point per lane at most");
@@ -862,11 +866,13 @@ LG_DEV void physics_substep(const KArgs &A, const float *tab, int lane_k, float 
 
 // ------------------------------------------------------------------ torques (legged_robot.py:371-395)
 template <int L> LG_DEV void pd_torques(const lg_params &P, const float *tab, const float (&act)[L], const float (&q)[L],
-                                        const float (&qd)[L], const float (&last_qd)[L], float (&tau)[L]) {
+                                        const float (&qd)[L], const float *last_qd /* this limb's last_dof_vel in memory (V control only) */, float (&tau)[L]) {
 #pragma unroll
     for (int j = 0; j < L; j++) {
         const float *tj = tab + j * LG_JS;
-        float a = act[j] * P.action_scale, t;
+        float aj = act[j];
+        if (L > 3) asm volatile("" : "+v"(aj));        // long chains: the scaled action is re-formed per sub-step, not held across the loop
+        float a = aj * P.action_scale, t;
         if (P.control_type == LG_CTRL_P) t = tj[J_KP] * (a + tj[J_Q0] - q[j]) - tj[J_KD] * qd[j];
         else if (P.control_type == LG_CTRL_V) t = tj[J_KP] * (a - qd[j]) - tj[J_KD] * (qd[j] - last_qd[j]) / P.sim_dt;
         else t = a;
@@ -1524,7 +1530,7 @@ __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
     const int k = ROLL ? (blockIdx.x * LG_BLOCK + lane) % K : k_wg;
     if constexpr (ROLL) { e = (blockIdx.x * LG_BLOCK + lane) / K; if (e >= N) e = N - 1; }
     const float *tab = lds_tab + k * Tab<T>::STRIDE;
-    const int d0 = e * ND + k * L;
+    int d0 = e * ND + k * L;
     const int64_t step = step0 + rt;
     const int sub0 = ROLL ? rt * P.decimation : 0;
     float *const roll_accum = ROLL ? A.roll.extras + (size_t)rt * (LG_NUM_REWARD_TERMS + 2) : nullptr;
@@ -1563,9 +1569,11 @@ __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
     }
     const float mu = 0.5f * ((B.friction_coeffs ? B.friction_coeffs[e] : 1.0f) + P.ground_friction);
     const float base_mass = A.base.mass + (B.base_mass_delta ? B.base_mass_delta[e] : 0.0f);
-    float last_qd[L];
+    float last_qd[L];                              // (long chains read it behind the sub-steps instead: L registers less across the physics)
+    if (L <= 3) {
 #pragma unroll
-    for (int j = 0; j < L; j++) last_qd[j] = B.last_dof_vel[d0 + j];
+        for (int j = 0; j < L; j++) last_qd[j] = B.last_dof_vel[d0 + j];
+    }
 
     // ---- decimation x (torque -> physics)   legged_robot.py:90-96
     float Frep[NREP][3], Fbase[3];
@@ -1583,7 +1591,7 @@ __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
     LG_PROF(PF_PROLOGUE);
 #pragma unroll 1
     for (int it = 0; it < P.decimation; it++) {
-        if (!NET) pd_torques<L>(P, tab, act, q, qd, last_qd, tau);
+        if (!NET) pd_torques<L>(P, tab, act, q, qd, B.last_dof_vel + d0, tau);
         if (NET || OFF) {
             if (NET) {
 #pragma unroll
@@ -1606,6 +1614,10 @@ __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
     }
 
     // =====================  post_physics_step  (legged_robot.py:106-137)  =====================
+    if (L > 3) {      // long chains: the per-env addresses of everything below are formed here, not above the sub-steps and held (spilled) across them
+        asm volatile("" : "+v"(e));
+        d0 = e * ND + k * L;
+    }
     int64_t ep_len = B.episode_length_buf[e] + 1;                                   // :114
     V3 blv = quat_rotate_inverse(root + 3, v3(root[7], root[8], root[9]));          // :118-121
     V3 bav = quat_rotate_inverse(root + 3, v3(root[10], root[11], root[12]));
@@ -1676,7 +1688,7 @@ __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
     // compute_reward :193-210 ; terms :872-969, cassie.py:43-46
     float last_act[L];
 #pragma unroll
-    for (int j = 0; j < L; j++) last_act[j] = B.last_actions[d0 + j];
+    for (int j = 0; j < L; j++) { last_act[j] = B.last_actions[d0 + j]; if (L > 3) last_qd[j] = B.last_dof_vel[d0 + j]; }
     float s_ar = 0, s_acc = 0, s_lim = 0, s_dv = 0, s_dvl = 0, s_tl = 0, s_tq = 0, s_ss = 0;
 #pragma unroll
     for (int j = 0; j < L; j++) {
