@@ -217,6 +217,13 @@ LG_DEV void wide_epilogue(const f32x16p (&acc)[TPW], const float *__restrict__ b
     }
 }
 
+// phase stamps of wave 0 of every workgroup (tools/ubench/chain_probe.hip, actor_probe.hip; -DLG_CHAIN_PROF builds only)
+#ifdef LG_CHAIN_PROF
+__device__ unsigned long long g_chain_prof[2048 * 16];
+#define CHAIN_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.y == 0) g_chain_prof[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CHAIN_STAMP(i) do { } while (0)
+#endif
 // K0S = ceil(num_obs / 16) k-steps of layer 0; H1T/H2T/H3T = hidden widths / 32.  Every wave's weight stream runs ahead of the
 // layer barriers: the ring of layer l+1 is primed before layer l's epilogue, so no layer starts with an empty pipeline.
 template <int K0S, int H1T, int H2T, int H3T>
@@ -231,36 +238,69 @@ __global__ void __launch_bounds__(64 * LG_PW_WAVES) k_policy_act_wide(const Poli
     const int wv = (wave + blockIdx.x) % NW;                       // which share of the output tiles this wave takes (rotates over workgroups)
     const int r0 = (blockIdx.x * 5) % K0S, r1 = (blockIdx.x * 5) % (2 * H1T), r2 = (blockIdx.x * 5) % (2 * H2T);
     const bool on2 = wv * T2 < H2T, on3 = wv * T3 < H3T;
-    WideStream<K0S, T1> s1;
-    s1.prime(W.wb[0], wv * T1, r0, lane);
+    CHAIN_STAMP(0);
     const int64_t step = A.step >= 0 ? A.step : (A.step_counter ? A.step_counter[0] + 1 : 0);
     int env = blockIdx.x * LG_PW_ENVS + (lane & 31);
     const bool live = env < A.num_envs;
     if (!live) env = A.num_envs - 1;
     const float *o = A.obs + (size_t)env * A.num_obs;
-    for (int s = wave; s < K0S; s += NW) {                         // layer-0 B operands from global, natural k order
-        float v[8];
+    WideStream<K0S, T1> s1;
+    s1.prime(W.wb[0], wv * T1, r0, lane);
+    for (int s = wave; s < K0S; s += NW) {                         // layer-0 B operands from global, natural k order (requesting them ahead of
+        float v[8];                                                // the ring, as the learner's chain does, changes nothing here: measured)
 #pragma unroll
         for (int i = 0; i < 8; i++) { const int k = 16 * s + 8 * h + i; v[i] = k < A.num_obs ? o[k] : 0.0f; }
         bf16x8g hi, lo;
         split8(v, hi, lo);
         xa[s][0][lane] = hi; xa[s][1][lane] = lo;
     }
+    // The exploration noise and the output biases of wave 0's lanes are formed HERE, while the first weights are still on their way, not
+    // behind the last layer where one wave would walk Philox, two logs, two sincos and four dependent loads alone (5 k of the kernel's 52 k cycles).
+    // lane (env, h), register i = 4ii + r (ii = 0, 1): action a = 8ii + 4h + r, i.e. group g = a >> 2 = 2ii + h of the f32 kernel's
+    // noise stream (rand4 sub-stream 100 + g): same samples from both builds for the same mean
+    float ns[2][4], by[2][4];                                        // std * eps (0 when deterministic), output bias
+    if (wave == 0) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ii++) {
+            const int g = 2 * ii + h;
+#pragma unroll
+            for (int r = 0; r < 4; r++) { ns[ii][r] = 0.0f; by[ii][r] = 0.0f; }
+            if (4 * g >= A.num_actions) continue;
+            float u[4];
+            rand4(A.seed ^ 0x9E3779B97F4A7C15ull, env, step, 100 + g, 0, u);
+            const float rad0 = sqrtf(-2.0f * __logf(fmaxf(u[0], 1e-12f))), rad1 = sqrtf(-2.0f * __logf(fmaxf(u[2], 1e-12f)));
+            float s0, c0, sn1, c1;
+            __sincosf(6.2831853f * u[1], &s0, &c0);
+            __sincosf(6.2831853f * u[3], &sn1, &c1);
+            const float eps[4] = {rad0 * c0, rad0 * s0, rad1 * c1, rad1 * sn1};
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int a = 4 * g + r;
+                if (a < A.num_actions) { by[ii][r] = W.bb[3][a]; ns[ii][r] = A.deterministic ? 0.0f : A.std[a] * eps[r]; }
+            }
+        }
+    }
     __syncthreads();
+    CHAIN_STAMP(1);
     f32x16p a1[T1];
     s1.run(W.wb[0], xa, wv * T1, r0, lane, a1);
+    CHAIN_STAMP(2);
     WideStream<2 * H1T, T2> s2;
     if (on2) s2.prime(W.wb[1], wv * T2, r1, lane);
     __builtin_amdgcn_sched_barrier(0);
     wide_epilogue<T1>(a1, W.bb[0], xb, wv * T1, lane);
+    CHAIN_STAMP(3);
     __syncthreads();
+    CHAIN_STAMP(4);
     f32x16p a2[T2];
     WideStream<2 * H2T, T3> s3;
     if (on2) s2.run(W.wb[1], xb, wv * T2, r1, lane, a2);
+    CHAIN_STAMP(5);
     if (on3) s3.prime(W.wb[2], wv * T3, r2, lane);
     __builtin_amdgcn_sched_barrier(0);
     if (on2) wide_epilogue<T2>(a2, W.bb[1], xa, wv * T2, lane);
     __syncthreads();
+    CHAIN_STAMP(6);
     f32x16p a3[T3];
     WideStream<2 * H3T, 1> s4;
     if (on3) s3.run(W.wb[2], xa, wv * T3, r2, lane, a3);
@@ -268,32 +308,25 @@ __global__ void __launch_bounds__(64 * LG_PW_WAVES) k_policy_act_wide(const Poli
     __builtin_amdgcn_sched_barrier(0);
     if (on3) wide_epilogue<T3>(a3, W.bb[2], xb, wv * T3, lane);
     __syncthreads();
+    CHAIN_STAMP(7);
     if (wave != 0) return;
     f32x16p y[1];
     s4.run(W.wb[3], xb, 0, 0, lane, y);
-    // lane (env, h), register i = 4ii + r (ii = 0, 1): action a = 8ii + 4h + r, i.e. group g = a >> 2 = 2ii + h of the f32 kernel's
-    // noise stream (rand4 sub-stream 100 + g): same samples from both builds for the same mean
+    CHAIN_STAMP(8);
 #pragma unroll
     for (int ii = 0; ii < 2; ii++) {
         const int g = 2 * ii + h;
-        if (4 * g >= A.num_actions) continue;
-        float u[4];
-        rand4(A.seed ^ 0x9E3779B97F4A7C15ull, env, step, 100 + g, 0, u);
-        const float rad0 = sqrtf(-2.0f * __logf(fmaxf(u[0], 1e-12f))), rad1 = sqrtf(-2.0f * __logf(fmaxf(u[2], 1e-12f)));
-        float s0, c0, sn1, c1;
-        __sincosf(6.2831853f * u[1], &s0, &c0);
-        __sincosf(6.2831853f * u[3], &sn1, &c1);
-        const float eps[4] = {rad0 * c0, rad0 * s0, rad1 * c1, rad1 * sn1};
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int a = 4 * g + r;
             if (a < A.num_actions && live) {
-                const float m = y[0][4 * ii + r] + W.bb[3][a], act = A.deterministic ? m : m + A.std[a] * eps[r];
+                const float m = y[0][4 * ii + r] + by[ii][r];
                 if (A.mean) A.mean[(size_t)env * A.num_actions + a] = m;
-                A.actions[(size_t)env * A.num_actions + a] = act;
+                A.actions[(size_t)env * A.num_actions + a] = m + ns[ii][r];
             }
         }
     }
+    CHAIN_STAMP(9);
 }
 
 // ------------------------------------------------------------------ the same chain as the LEARNER's forward pass
@@ -385,12 +418,6 @@ LG_DEV void chain_epilogue2(const f32x16p (&acc)[2], const ChainBias &B, bf16x8g
     }
 }
 
-#ifdef LG_CHAIN_PROF
-__device__ unsigned long long g_chain_prof[2048 * 16];
-#define CHAIN_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.y == 0) g_chain_prof[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define CHAIN_STAMP(i) do { } while (0)
-#endif
 template <int K0S>                                               // hidden widths 512-256-128 (16 / 8 / 4 tiles), 8 waves
 __global__ void __launch_bounds__(64 * LG_PW_WAVES) k_mlp_chain_fwd64(const ChainArgs C) {
     static_assert(LG_PW_WAVES == 8 && K0S <= 16, "one layer-1 tile per wave; x0 fits the 16 k-step buffer");
