@@ -94,24 +94,35 @@ LG_DEV void policy_forward(const PolicyArgs &A, float4 (*xa)[64], float4 (*xb)[6
     mlp_layer<D1T, D2T, true>(A.w[1], A.b[1], xb, xa, wave, lane);
     __syncthreads();
     mlp_layer<D2T, D3T, true>(A.w[2], A.b[2], xa, xb, wave, lane);
+    // The exploration noise std * eps (Philox -> Box-Muller: two logs, two sincos, four loads of std) is drawn by the LAST wave -- which has
+    // no output tile in this layer of the 48-128-64-32 actor -- into the still unused xy tile, not by wave 0 behind the output layer, where
+    // everything waits for the actions.
+    if (wave == LG_POLICY_WAVES - 1) {
+        float u[4];
+        rand4(A.seed ^ 0x9E3779B97F4A7C15ull, env, step, 100 + g, 0, u);
+        float rad0 = sqrtf(-2.0f * __logf(fmaxf(u[0], 1e-12f))), rad1 = sqrtf(-2.0f * __logf(fmaxf(u[2], 1e-12f)));
+        float s0, c0, s1, c1;
+        __sincosf(6.2831853f * u[1], &s0, &c0);
+        __sincosf(6.2831853f * u[3], &s1, &c1);
+        const float eps[4] = {rad0 * c0, rad0 * s0, rad1 * c1, rad1 * s1};
+        float ns[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) { const int a = 4 * g + r; ns[r] = (a < A.num_actions && !A.deterministic) ? A.std[a] * eps[r] : 0.0f; }
+        xy[0][lane] = make_float4(ns[0], ns[1], ns[2], ns[3]);
+    }
     __syncthreads();
     if (wave != 0) return;
+    const float4 nv = xy[0][lane];                                 // lane (env, g): std * eps of actions 4g .. 4g + 3 (read before the output layer reuses the tile)
+    const float ns[4] = {nv.x, nv.y, nv.z, nv.w};
     mlp_layer<D3T, 1, false>(A.w[3], A.b[3], xb, xy, 0, lane);
     const float4 yv = xy[0][lane];                                 // written by this lane
     const float y[4] = {yv.x, yv.y, yv.z, yv.w};
-    // lane (env, g) now holds mean[4g + r]; sample a = mean + std * eps  (Philox -> Box-Muller)
-    float u[4];
-    rand4(A.seed ^ 0x9E3779B97F4A7C15ull, env, step, 100 + g, 0, u);
-    float rad0 = sqrtf(-2.0f * __logf(fmaxf(u[0], 1e-12f))), rad1 = sqrtf(-2.0f * __logf(fmaxf(u[2], 1e-12f)));
-    float s0, c0, s1, c1;
-    __sincosf(6.2831853f * u[1], &s0, &c0);
-    __sincosf(6.2831853f * u[3], &s1, &c1);
-    float eps[4] = {rad0 * c0, rad0 * s0, rad1 * c1, rad1 * s1};
+    // lane (env, g) now holds mean[4g + r]; a = mean + std * eps
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         int a = 4 * g + r;
         if (a < A.num_actions) {
-            float m = y[r], act = A.deterministic ? m : m + A.std[a] * eps[r];
+            float m = y[r], act = m + ns[r];
             if (lds_act) lds_act[a][lane & 15] = act;
             if (live) {
                 if (A.mean) A.mean[(size_t)env * A.num_actions + a] = m;
