@@ -337,16 +337,19 @@ __global__ void __launch_bounds__(64 * LG_TRAIN_WAVES * SLOTS) k_mlp_train(const
     };
     const int stride = gridDim.x * SLOTS, n_iter = (A.n_tiles + stride - 1) / stride;     // uniform trip count: barriers inside
     int rt = blockIdx.x * SLOTS + slot;
-    if (rt < A.n_tiles) request(rt, row_index(rt));                // the only gather that waits for its index in line ...
-    if (rt + stride < A.n_tiles) src_next = row_index(rt + stride);
-    LG_TR();
-    // ... and it is in flight while the weights are copied to LDS
+    // Vector memory loads return in order: the weights are requested FIRST, the first tile's gather (row index, then the row: two dependent
+    // trips, the only gather that waits for its index in line) behind them -- the other way round the 72 KB of weights could not be stored
+    // to LDS before the gather had come back (prologue 9.7 us of the kernel's 62, phase stamps of the -DLG_PROFILE build).
     {
         constexpr int NT = 64 * LG_TRAIN_WAVES * SLOTS;
         LdsFill<D0T, D1T, NT> f0; LdsFill<D1T, D2T, NT> f1; LdsFill<D2T, D3T, NT> f2; LdsFill<D3T, 1, NT> f3;
         f0.load(N.w[0], N.b[0], d0, d1, threadIdx.x); f1.load(N.w[1], N.b[1], d1, d2, threadIdx.x);
         f2.load(N.w[2], N.b[2], d2, d3, threadIdx.x); f3.load(N.w[3], N.b[3], d3, d4, threadIdx.x);
+        const int64_t src0 = rt < A.n_tiles ? row_index(rt) : 0;
+        if (rt + stride < A.n_tiles) src_next = row_index(rt + stride);
+        LG_TR();
         f0.store(wl0, threadIdx.x); f1.store(wl1, threadIdx.x); f2.store(wl2, threadIdx.x); f3.store(wl3, threadIdx.x);
+        if (rt < A.n_tiles) request(rt, src0);
     }
     LG_TR();
     // The row-tile loop is compiled once per role: with the role a compile-time constant every tile index and LDS tile address
