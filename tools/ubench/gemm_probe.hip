@@ -93,8 +93,41 @@ static void run_dx(int mb, int N, int K) {               // G_l[mb][N] = (G_{l+1
            2.0 * 2.0 * mb * N * K / us * 1e-6, worst);
 }
 
+static void run_outbwd(int mb, int chunks) {            // the <= 16-wide output layer: G_2 = (dZ_3 W_3) * elu'(A_2), dW_3 / db_3 partials
+    lg::OutBwdArgs o; memset(&o, 0, sizeof o);
+    o.mb = mb;
+    std::vector<float> hdz, hw, ha;
+    for (int n = 0; n < 2; n++) {
+        lg::OutBwdNet &q = o.net[n];
+        q.N = n == 0 ? 12 : 1; q.K = 128; q.ld = (128 + 1 + 3) & ~3; q.chunks = chunks; q.rows_per_chunk = (mb + chunks - 1) / chunks;
+        q.dz = dev_random((size_t)mb * q.N, 41 + n, 0.05f, n == 0 ? &hdz : nullptr);
+        q.w = dev_random((size_t)q.N * 128, 43 + n, 0.1f, n == 0 ? &hw : nullptr);
+        q.act = dev_random((size_t)mb * 128, 45 + n, 1.0f, n == 0 ? &ha : nullptr);
+        CK(hipMalloc(&q.g, (size_t)mb * 128 * 4)); CK(hipMalloc(&q.part, (size_t)chunks * q.N * q.ld * 4));
+    }
+    const double us = time_us([&] { hipLaunchKernelGGL((lg::k_wide_out_bwd<LG_OUT_MAXN>), dim3(chunks, 2), dim3(256), 0, 0, o); });
+    std::vector<float> hg((size_t)mb * 128), hp((size_t)chunks * 12 * o.net[0].ld);
+    CK(hipMemcpy(hg.data(), o.net[0].g, hg.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(hp.data(), o.net[0].part, hp.size() * 4, hipMemcpyDeviceToHost));
+    double worst = 0.0;
+    for (int t = 0; t < 16; t++) {
+        const int r = (t * 1531 + 7) % mb, k = (t * 29 + 3) % 128;
+        double ref = 0.0, mag = 1e-30;
+        for (int n = 0; n < 12; n++) { const double v = (double)hdz[(size_t)r * 12 + n] * hw[(size_t)n * 128 + k]; ref += v; mag += fabs(v); }
+        const double x = ha[(size_t)r * 128 + k];
+        worst = fmax(worst, fabs(hg[(size_t)r * 128 + k] - ref * (x > 0 ? 1.0 : x + 1.0)) / mag);
+        const int n = t % 12;                                                       // dW_3[n][k] over all chunks
+        double refw = 0.0, gotw = 0.0, magw = 1e-30;
+        for (int rr = 0; rr < mb; rr++) { const double v = (double)hdz[(size_t)rr * 12 + n] * ha[(size_t)rr * 128 + k]; refw += v; magw += fabs(v); }
+        for (int c = 0; c < chunks; c++) gotw += hp[((size_t)c * 12 + n) * o.net[0].ld + k];
+        worst = fmax(worst, fabs(gotw - refw) / magw);
+    }
+    printf("out-layer backward, %d rows, %d chunks: %6.1f us  %.2f TB/s of A_2 read + G_2 written  err %.1e\n", mb, chunks, us, 2.0 * 2.0 * mb * 128 * 4 / us * 1e-6, worst);
+}
+
 int main(int argc, char **argv) {
     const int mb = argc > 1 ? atoi(argv[1]) : 24576;
+    run_outbwd(mb, 256); run_outbwd(mb, 512); run_outbwd(mb, 1024);
     run_dw(mb, 512, 235, 236);
     run_dw(mb, 256, 512, 512);
     run_dw(mb, 128, 256, 256);
