@@ -1625,6 +1625,21 @@ __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
     float cmd[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) cmd[i] = B.commands[(size_t)e * 4 + i];
+    // Height-field builds of the short chains: everything else the reward / reset block reads from memory is requested here, in front of the
+    // two barriers of the height crew, not at its point of use behind them (a barrier is a fence: the compiler cannot lift a load over it,
+    // and each was a bare L2 round trip): 66.0 -> 65.3 us on the same box.  Cassie's kernels have no register to hold them that long
+    // (+23 spilled) and the plane kernels get slower (51.7 -> 52.2 us, same box: the allocation shifts): they read them where they are used.
+    constexpr bool EARLY_POST = L <= 3 && HF;
+    float last_act[L], fat, origin[3];
+    uint8_t lc;
+    if (EARLY_POST) {
+#pragma unroll
+        for (int j = 0; j < L; j++) last_act[j] = B.last_actions[d0 + j];
+        fat = B.feet_air_time[(size_t)e * K + k];
+        lc = B.last_contacts[(size_t)e * K + k];
+#pragma unroll
+        for (int i = 0; i < 3; i++) origin[i] = B.env_origins[(size_t)e * 3 + i];
+    }
     // _get_heights :831-869, by all four waves (HeightCrew); this wave is virtual lane k of its env
     sh.pose[lane][0] = root[0]; sh.pose[lane][1] = root[1]; sh.pose[lane][2] = root[2]; sh.pose[lane][3] = root[5]; sh.pose[lane][4] = root[6];
     __syncthreads();                                               // P1 (also publishes the helpers' uniforms)
@@ -1686,9 +1701,10 @@ __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
     const bool reset = contact_term || time_out || bad;
 
     // compute_reward :193-210 ; terms :872-969, cassie.py:43-46
-    float last_act[L];
+    if (!EARLY_POST) {
 #pragma unroll
-    for (int j = 0; j < L; j++) { last_act[j] = B.last_actions[d0 + j]; if (L > 3) last_qd[j] = B.last_dof_vel[d0 + j]; }
+        for (int j = 0; j < L; j++) { last_act[j] = B.last_actions[d0 + j]; if (L > 3) last_qd[j] = B.last_dof_vel[d0 + j]; }
+    }
     float s_ar = 0, s_acc = 0, s_lim = 0, s_dv = 0, s_dvl = 0, s_tl = 0, s_tq = 0, s_ss = 0;
 #pragma unroll
     for (int j = 0; j < L; j++) {
@@ -1711,8 +1727,7 @@ __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
     int stumble = group_or<K>(sqrtf(ff[0] * ff[0] + ff[1] * ff[1]) > 5.0f * fabsf(ff[2]) ? 1 : 0);
     float nfly = group_sum<K>(ff[2] > 0.1f ? 1.0f : 0.0f);
     float air = 0.0f;
-    float fat = B.feet_air_time[(size_t)e * K + k];
-    uint8_t lc = B.last_contacts[(size_t)e * K + k];
+    if (!EARLY_POST) { fat = B.feet_air_time[(size_t)e * K + k]; lc = B.last_contacts[(size_t)e * K + k]; }
     if (P.reward_scale[LG_REW_FEET_AIR_TIME] != 0.0f) {
         bool contact = ff[2] > 1.0f, filt = contact || lc;
         lc = (uint8_t)contact;
@@ -1762,7 +1777,7 @@ __global__ void __launch_bounds__(NW * LG_BLOCK) k_step(const KArgs A) {
 
     LG_PROF(PF_POST_REWARD);
     // reset_idx for terminated envs (predicated epilogue) :128-129, anymal.py:56-60
-    float origin[3] = {B.env_origins[(size_t)e * 3], B.env_origins[(size_t)e * 3 + 1], B.env_origins[(size_t)e * 3 + 2]};
+    if (!EARLY_POST) { origin[0] = B.env_origins[(size_t)e * 3]; origin[1] = B.env_origins[(size_t)e * 3 + 1]; origin[2] = B.env_origins[(size_t)e * 3 + 2]; }
     if (reset) {
         int level = 0; bool level_changed = false;
         reset_values<T>(A, tab, e, k, step, root, q, qd, cmd, origin, level, level_changed, NW > 1 ? &reset_rand : nullptr, lane);
