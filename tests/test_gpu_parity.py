@@ -522,7 +522,7 @@ def test_full_post_physics_matches_reference_fixture(task, golden_dir):
     check_full_outputs(lambda k: get(d, k), g, names, cfg, w is not None)
 
 
-@pytest.mark.parametrize("task", ["anymal_c_flat", "anymal_c_rough"])
+@pytest.mark.parametrize("task", ["anymal_c_flat", "anymal_c_rough", "cassie"])
 def test_reset_idx_matches_reference_fixture(task, golden_dir):
     """lg_reset_idx (k_reset) against the reference's own reset_idx(env_ids) (:147-191) on a subset of envs."""
     from tests.test_oracle_reset_half import check_reset_idx_outputs

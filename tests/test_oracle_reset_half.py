@@ -108,7 +108,7 @@ def test_full_post_physics_matches_reference_fixture(task, oracle_lib, golden_di
     check_full_outputs(lambda k: o.buf[k], g, names, cfg, w is not None)
 
 
-@pytest.mark.parametrize("task", ["anymal_c_flat", "anymal_c_rough"])
+@pytest.mark.parametrize("task", ["anymal_c_flat", "anymal_c_rough", "cassie"])
 def test_reset_idx_matches_reference_fixture(task, oracle_lib, golden_dir):
     g = np.load(os.path.join(golden_dir, f"reset_idx_{task}.npz"))
     N = g["in_root_states"].shape[0]
